@@ -1,0 +1,69 @@
+"""CPU: the oracle (oracle/stil_oracle.py) reproduces the golden vectors that
+oracle/make_golden.py recorded from the REAL reference (STiLModel.training_step +
+backward + Adam), for every case incl. injected dropout masks."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import stil_oracle as O
+from oracle.make_golden import CASES, SCALARS, TENSORS, build_case
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _close(a, b, tol):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = np.abs(b).max() if b.size else 0.0
+    return np.all(np.abs(a - b) <= tol * (1.0 + np.abs(b) + scale))
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_matches_reference_golden(name):
+    fx = np.load(os.path.join(GOLD, name + ".npz"))
+    hp, sd, batch, epoch, mask_random, mi_masks = build_case(name)
+    assert int(fx["meta_epoch"]) == epoch
+    out = O.full_step(sd, {}, 1, batch, hp, epoch, mask_random, mi_masks)
+    for k in SCALARS:
+        assert _close(out[k].numpy(), fx["out_" + k], 2e-5), k
+    for k in TENSORS:
+        a, b = out[k].numpy(), fx["out_" + k]
+        if b.dtype == np.bool_:
+            assert np.array_equal(a, b), k
+        else:
+            assert _close(a, b, 2e-5), k
+    for key in fx.files:
+        if key.startswith("gnorm_"):
+            g = out["grads"].get(key[6:])
+            n = 0.0 if g is None else float(g.double().norm())
+            assert abs(n - float(fx[key])) <= 1e-4 * (1e-6 + float(fx[key])) + 1e-7, key
+        elif key.startswith("grad_"):
+            assert _close(out["grads"][key[5:]].numpy(), fx[key], 5e-5), key
+        elif key.startswith("ssum_"):
+            v = sd[key[5:]].double()
+            ref_abs = float(fx["sabs_" + key[5:]])
+            assert abs(float(v.sum()) - float(fx[key])) <= 2e-5 * (1.0 + ref_abs), key
+
+
+def test_epoch_end_commits_prototypes():
+    hp = O.default_hparams(num_classes=3, projection_dim=4)
+    sd = {"prototypes": torch.zeros(3, 4), "prototypes_sum": torch.arange(12.0).reshape(3, 4),
+          "prototypes_count_sum": torch.tensor([[1.0], [2.0], [4.0]])}
+    O.training_epoch_end(sd)
+    assert torch.allclose(sd["prototypes"][2], torch.tensor([2.0, 2.25, 2.5, 2.75]))
+    assert float(sd["prototypes_sum"].abs().sum()) == 0.0
+    sd["prototypes_count_sum"][1] = 0.0
+    with pytest.raises(AssertionError):  # STiLModel.py:412
+        O.training_epoch_end(sd)
+
+
+def test_state_dict_layout_matches_reference_appendix_a():
+    hp = O.default_hparams()
+    sd = O.init_state(hp)
+    assert len(sd) == 831
+    assert sum(1 for k in sd if k.startswith("model.")) == 406
+    assert sum(1 for k in sd if k.startswith("ema.")) == 406
+    n_train = sum(sd[k].numel() for k in O.trainable_keys(sd))
+    assert abs(n_train - 46.72e6) < 0.02e6
