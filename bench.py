@@ -1,0 +1,161 @@
+"""bench.py -- training samples/s (labelled + unlabelled) of the DVM-STiL training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = zero_grad -> STiLModel.training_step -> backward -> (RCCL grad all-reduce) -> Adam on one batch of
+synthetic input already resident in HBM (224x224 images U[0,1), 16 categorical + 48
+continuous columns, K = 286, B_l = B/8, current_epoch > start_epoch so every loss term is live, MI-layer
+dropout active).  Weak scaling: every rank runs `--batch` (default 256, BASELINE.json configs[1]) samples.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel gemm_nt_kernel<2,2> (fp32-exact MFMA
+implicit GEMM): algorithmic FLOPs of its launches / their HIP-event durations, both taken on the launch
+stream during the LAST timed step.  `cpu_baseline` is the oracle (a CPU port validated against the
+reference) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FLOPS_PER_SAMPLE = {(224, 64): 41.475e9, (128, 17): 13.155e9}  # student fwd + teacher fwd + bwd
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (labelled + unlabelled)")
+    ap.add_argument("--img", type=int, default=224)
+    ap.add_argument("--ncat", type=int, default=16)
+    ap.add_argument("--ncon", type=int, default=48)
+    ap.add_argument("--classes", type=int, default=286)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--breakdown", action="store_true", help="also print per-entry-point GPU time of the last step (stderr)")
+    return ap.parse_args()
+
+
+def cpu_baseline(field_lengths, classes, img, batch, steps=2):
+    """The oracle's full step (training_step + backward + Adam) on the host cores: a bounded sample of the workload."""
+    from oracle import stil_oracle as O
+    hp = O.default_hparams(field_lengths=field_lengths, num_classes=classes, img_size=img, batch_size=batch, start_epoch=0)
+    sd = O.init_state(hp, seed=0)
+    g = torch.Generator().manual_seed(1)
+    sd["prototypes"] = torch.nn.functional.normalize(torch.randn(classes, hp.projection_dim, generator=g))
+    b = O.synthetic_batch(hp, batch, seed=2022)
+    opt = {}
+    O.full_step(sd, opt, 1, b, hp, 1)  # warm-up
+    t0 = time.perf_counter()
+    for i in range(steps):
+        O.full_step(sd, opt, 2 + i, b, hp, 1)
+    dt = (time.perf_counter() - t0) / steps
+    return dict(value=round(batch / dt, 3), unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{steps} timed steps (1 warm-up) of batch {batch} at the workload's shapes "
+                       f"({img}px, {len(field_lengths)} columns, K={classes}); oracle/stil_oracle.py full_step, torch {torch.__version__} CPU",
+                s_per_step=round(dt, 3))
+
+
+def main():
+    a = parse()
+    from stil_tta_amd import STiLModel
+    from stil_tta_amd._lib import lib
+    from stil_tta_amd.driver import init_distributed, train_step, synthetic_batch
+    from stil_tta_amd.flat import StilAdam
+
+    rank, world, local = init_distributed()
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path in the product)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    fl = [8] * a.ncat + [1] * a.ncon
+    torch.manual_seed(2022)
+    m = STiLModel(dict(field_lengths=fl, num_classes=a.classes, img_size=a.img, batch_size=a.batch, start_epoch=35,
+                       repeat_ratio=1.0, seed=2022 + rank))
+    m.setup_device(dev)
+    m.train()
+    m.current_epoch = 36  # > start_epoch: every loss term of STiLModel.py:345 is live
+    g = torch.Generator().manual_seed(7)
+    m.prototypes.copy_(torch.nn.functional.normalize(torch.randn(a.classes, 128, generator=g)).to(dev))
+    opt = StilAdam(m.flat, lr=1e-4)
+    batch = synthetic_batch(fl, a.classes, a.batch, a.img, seed=2022 + rank, device=dev)
+
+    for _ in range(a.warmup):
+        train_step(m, opt, batch)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    L = lib()
+    prof = None
+    for s in range(a.steps):
+        if s == a.steps - 1:
+            L.begin_profile()  # HIP events around every C-ABI launch of the last timed step (same stream)
+        train_step(m, opt, batch)
+        if s == a.steps - 1:
+            torch.cuda.synchronize()
+            prof = L.end_profile()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    loss = float(m.last["loss"])
+    assert loss == loss, "loss is NaN"
+
+    if rank == 0:
+        value = a.batch * world * a.steps / dt
+        # dominant kernel: gemm_nt_kernel<2,2>
+        g22 = [(ms, meta[1]) for name, ms, meta in prof if name == "gemm_nt" and meta and meta[0] == 22]
+        tsum = sum(x[0] for x in g22) * 1e-3
+        fsum = sum(x[1] for x in g22)
+        achieved = fsum / tsum / 1e12 if tsum > 0 else 0.0
+        roof = dict(bound="mfma", kernel="gemm_nt_kernel<2,2>", achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS,
+                    unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                    launches_per_step=len(g22), avg_launch_us=round(tsum / max(1, len(g22)) * 1e6, 2),
+                    flops_per_step=fsum, share_of_step_time=round(tsum / (dt / a.steps), 4))
+        fps = FLOPS_PER_SAMPLE.get((a.img, a.ncat + a.ncon))
+        out = dict(metric="training samples/sec (labeled+unlabeled) for DVM STiL", value=round(value, 2), unit="samples/s",
+                   n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3),
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload=f"config_dvm_STiL ResNet-50 + Transformer tabular, batch {a.batch}/GPU "
+                                        f"({a.batch // 8} labelled + {a.batch - a.batch // 8} unlabelled), {a.img}x{a.img} + "
+                                        f"{a.ncat + a.ncon} columns, K={a.classes}, epoch > start_epoch, MI dropout on",
+                               global_batch=a.batch * world, parallelism=f"dp{world}", precision="fp32-exact MFMA"),
+                   roofline=roof, loss=round(loss, 5))
+        if fps:
+            out["step_tflops_algorithmic"] = round(value * fps / 1e12, 2)
+            out["step_frac_of_fp32_mfma_peak"] = round(value * fps / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4)
+        if a.breakdown:
+            agg = {}
+            for name, ms, meta in prof:
+                key = name if name != "gemm_nt" else f"gemm_nt<{meta[0]}>"
+                c = agg.setdefault(key, [0, 0.0])
+                c[0] += 1; c[1] += ms
+            tot = sum(v[1] for v in agg.values())
+            for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                print(f"  {k:28s} {v[0]:5d} launches {v[1]:9.3f} ms {100 * v[1] / tot:5.1f}%", file=sys.stderr)
+            print(f"  sum of C-ABI kernels {tot:.3f} ms of {dt / a.steps * 1e3:.3f} ms/step", file=sys.stderr)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(fl, a.classes, a.img, a.cpu_batch)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,165 @@
+/* libstil_hip.so -- C ABI of the MI355X (gfx950) kernels behind the STiL training step.
+ *
+ * The reference (kgutjahr/STiL-TTA) is pure PyTorch: it has no FFI, its "plugin API" is
+ * LightningModule.training_step.  Each entry point below therefore replaces the ATen op
+ * sequence issued at the cited reference lines; stil_tta_amd/ops.py binds them 1:1 (ctypes)
+ * and stil_tta_amd/stil_model.py re-assembles STiLModel.training_step from them.
+ *
+ * Conventions
+ *   - all tensors fp32, contiguous unless a leading dimension (ld*) is given; device pointers;
+ *   - caller owns every buffer (PyTorch allocator); the library allocates nothing and keeps
+ *     no mutable global state apart from a one-time kernel attribute;
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t), never synchronises;
+ *   - return 0 = ok, <0 = error (-1 invalid argument, -2 unsupported shape, -3 HIP error);
+ *     stil_last_error() returns the thread-local message; nothing throws across the boundary;
+ *   - `accumulate` != 0 means "+=" into the destination gradient slot;
+ *   - reductions use fixed-order sums (no float atomics): results are run-to-run bit-stable.
+ *
+ * NHWC activation layout: a feature map [N,H,W,C] is the row-major matrix [N*H*W, C].
+ */
+#ifndef STIL_HIP_H
+#define STIL_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* stil_last_error(void);
+int stil_version(void);
+int stil_device_count(void);
+
+/* ---- GEMM / convolution (fp32-exact MFMA, v_mfma_f32_32x32x2_f32) -------------------------
+ * C[M,N] = act( (alpha * Agather[M,K] . W[N,K]^T) * scale[n] + shift[n] + bias[n] + resid[m,n] )
+ * Agather row m = (n, oy, ox) over an NHWC source [*, srcH, srcW, srcC] (row stride lda),
+ * k = (ky*KW + kx)*srcC + c.  mode 0: iy = oy*stride - pad + ky (forward);  mode 1: iy = (oy + pad - ky)/stride
+ * when divisible (input-gradient of a strided conv).  A plain GEMM is srcH=srcW=OH=OW=KH=KW=1, srcC=K.
+ * `pre` (optional) receives the value before the activation.  act: 0 none, 1 ReLU, 2 GELU(erf).
+ * Replaces nn.Conv2d / nn.Linear forward and input-gradient: models/resnets.py:112-132,248-260,
+ * models/Transformer.py:27-33,63-88, STiLModel_backbone.py:19-32,139,153-155. */
+int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                 int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad, int mode,
+                 const float* bias, const float* scale, const float* shift, const float* resid, int ldr,
+                 float* pre, int act, float alpha, void* stream);
+
+/* tile variant stil_gemm_nt launches for an [M,N] output: 22 = 128x128, 21 = 128x64, 11 = 64x64 (bench bookkeeping) */
+int stil_gemm_nt_variant(int M, int N);
+
+/* Weight gradient  dW (+)= dY[M,N]^T . Xgather[M,K]  (split over M, slab partials + ordered reduce).
+ * KH*KW > 1: dW is written in the reference layout (N, srcC, KH, KW); else [N, Kdst] (first Kdst columns). */
+size_t stil_wgrad_workspace_bytes(int M, int N, int K);
+int stil_wgrad_tn(const float* dY, const float* X, float* dW, int M, int N, int K, int ldy, int ldx,
+                  int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad,
+                  int Kdst, int accumulate, float* workspace, size_t workspace_bytes, void* stream);
+
+/* out[n] (+)= scale * sum_m X[m,n]   (bias gradients) */
+size_t stil_colsum_workspace_bytes(int M, int N);
+int stil_colsum(const float* X, float* out, int M, int N, int ld, int accumulate, float scale,
+                float* workspace, size_t workspace_bytes, void* stream);
+
+/* (Cout,Cin,KH,KW) -> [Cout][KH*KW][Cin] (forward operand) and [Cin][KH*KW][Cout] (dgrad operand) */
+int stil_conv_weight_layout(const float* w, float* w_fwd, float* w_dgrad, int Cout, int Cin, int KH, int KW,
+                            void* stream);
+int stil_im2col_nchw(const float* x, float* col, int N, int Cin, int H, int W, int OH, int OW, int KH,
+                     int KW, int stride, int pad, int Kp, void* stream);
+int stil_transpose(const float* in, float* out, int R, int C, void* stream);
+
+/* ---- BatchNorm2d (NHWC rows), ReLU, residual, max-pool: models/resnets.py:112-132,248-252 ----
+ * stats: [4,C] = mean, rstd, a=gamma*rstd, b=beta-mean*a.  Train forward also updates the running
+ * statistics (momentum, unbiased variance) and num_batches_tracked. z = relu?(x*a + b + resid). */
+size_t stil_bn_workspace_bytes(int M, int C);
+int stil_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, long long* num_batches_tracked, const float* resid, float* z,
+                      float* stats, int M, int C, int relu, float eps, float momentum, float* workspace,
+                      size_t workspace_bytes, void* stream);
+int stil_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                        const float* running_var, float* ab, int C, float eps, void* stream);
+int stil_bn_train_bwd(const float* dz, const float* z, const float* x, const float* gamma,
+                      const float* stats, float* dx, float* gout, float* dgamma, float* dbeta, float* coef,
+                      int M, int C, int relu, int accumulate, float* workspace, size_t workspace_bytes,
+                      void* stream);
+int stil_maxpool3x3s2_fwd(const float* x, float* y, unsigned char* idx, int N, int H, int W, int C, int OH,
+                          int OW, void* stream);
+int stil_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, float* dx, int N, int H, int W, int C,
+                          int OH, int OW, void* stream);
+
+/* ---- transformer pieces: models/Transformer.py:63-88,165-174,240-259; disentangle_transformer.py:49-169 */
+int stil_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean_rstd,
+                       int rows, int D, float eps, void* stream);
+size_t stil_layernorm_bwd_workspace_bytes(int rows, int D);
+int stil_layernorm_bwd(const float* g, const float* x, const float* gamma, const float* mean_rstd,
+                       float* dx, float* dgamma, float* dbeta, int rows, int D, int accumulate,
+                       float* workspace, size_t workspace_bytes, void* stream);
+/* qkv: [B,T,3,H,d]. Queries are tokens [q_off,q_off+Sq), keys/values tokens [kv_off,kv_off+Skv).
+ * out: [B,T,H*d] (query rows only); probs: [B,H,Sq,Skv] softmax before dropout; mask: optional keep-mask.
+ * Backward ACCUMULATES into dqkv (zero it before the first window). */
+int stil_attention_fwd(const float* qkv, float* out, float* probs, const unsigned char* mask, int B, int T,
+                       int H, int d, int q_off, int Sq, int kv_off, int Skv, float scale, float drop_p,
+                       void* stream);
+int stil_attention_bwd(const float* dout, const float* qkv, const float* probs, const unsigned char* mask,
+                       float* dqkv, int B, int T, int H, int d, int q_off, int Sq, int kv_off, int Skv,
+                       float scale, float drop_p, void* stream);
+/* kind 1: dx = dy*(ref>0) (ref = ReLU output); kind 2: dx = dy*gelu'(ref) (ref = pre-activation) */
+int stil_act_bwd(const float* dy, const float* ref, float* dx, long n, int kind, void* stream);
+/* out = resid + x * emask[i] * rmask[i/rowlen] * scale   (nn.Dropout / drop_path / residual add) */
+int stil_drop_add(const float* x, const float* resid, const unsigned char* emask, const unsigned char* rmask,
+                  float* out, long n, int rowlen, float scale, void* stream);
+int stil_axpby(const float* x, const float* y, float* out, long n, float a, float b, void* stream);
+int stil_rng_mask(unsigned char* out, long n, unsigned long long seed, unsigned long long offset, float p,
+                  void* stream);
+int stil_tab_embed_fwd(const float* x, const int* cat_offsets, const float* cat_emb, const float* con_w,
+                       const float* con_b, const float* cls, const float* colemb, float* h, int B,
+                       int ncols, int ncat, int D, void* stream);
+size_t stil_tab_embed_bwd_workspace_bytes(int ncols, int D);
+int stil_tab_embed_bwd(const float* g, const float* x, const int* cat_offsets, const int* rowcol,
+                       int n_emb_rows, float* d_emb, float* d_con_w, float* d_con_b, float* d_cls,
+                       float* d_colemb, int B, int ncols, int ncat, int D, int accumulate, float* workspace,
+                       size_t workspace_bytes, void* stream);
+int stil_tokmean_fwd(const float* x, float* y, int B, int T, int D, void* stream);
+int stil_tokmean_bwd(const float* g, float* dx, int B, int T, int D, void* stream);
+
+/* ---- loss tail: STiLModel.py:259-303,339,374-381; utils/clip_loss.py; utils/prototype_loss.py; club.py */
+int stil_ce_hard(const float* logits, int ld, const long long* labels, float* row_loss, float* dlogits,
+                 int ldd, int rows, int K, float inv_rows, void* stream);
+int stil_ce_soft(const float* logits, int ld, const float* targets, int ldq, const float* row_w,
+                 float* row_loss, float* dlogits, int ldd, int rows, int K, float inv_rows, void* stream);
+int stil_reduce_sum(const float* x, int n, float scale, float* out, int accumulate, void* stream);
+int stil_scale_dev(const float* x, const float* g_dev, float c, float* out, long n, void* stream);
+int stil_l2norm_fwd(const float* x, float* y, float* norms, int rows, int D, void* stream);
+int stil_l2norm_bwd(const float* g, const float* y, const float* norms, float* dx, int rows, int D,
+                    void* stream);
+int stil_clip_fwd(const float* Z, float* lse, float* terms, float* loss, int B, float lam0, float lam1,
+                  void* stream);
+int stil_clip_bwd(const float* Z, const float* lse, const float* g_dev, float* dZ, int B, float lam0,
+                  float lam1, void* stream);
+int stil_club_fwd(const float* mu, const float* y, const float* ybar, float* rows_tmp, float* out2, int R,
+                  int D, void* stream);
+int stil_club_bwd(const float* mu, const float* y, const float* ybar, const float* mubar,
+                  const float* g_club_dev, const float* g_est_dev, float* dmu, float* dy, int R, int D,
+                  void* stream);
+/* flags: [Bu,4] = {case id 1..4 (case1, case2_i, case2_t, case3), mask1, confident-for-prototypes, 0};
+ * w3: [3,Bu] row weights of the unlabelled CE terms (multimodal, imaging, tabular). */
+int stil_cgpl_pgls(const float* zm, const float* zi, const float* zt, int ldz, const float* feat_u,
+                   const float* prototypes, const unsigned char* mask_random, float* pseudo_label,
+                   float* pseudo_orig, float* prediction, unsigned char* flags, int* hard, float* w3, int Bu,
+                   int K, int Dp, float rate_pseudo, float T, float th, int use_pseudo, void* stream);
+int stil_proto_loss(const float* feat, const float* prototypes, const int* hard, const unsigned char* conf,
+                    float* row_loss, float* dfeat_unit, int rows, int K, int Dp, float T, void* stream);
+/* class_sum_cnt: [K, Dp+1] (last column = counts); labelled rows (< B_l) are divided by repeat_ratio */
+int stil_proto_accum(const float* feat_e, const int* hard, const unsigned char* conf, float* class_sum_cnt,
+                     int B, int B_l, int K, int Dp, float repeat_ratio, void* stream);
+int stil_proto_add(const float* class_sum_cnt, float* prototypes_sum, float* prototypes_count_sum, int K,
+                   int Dp, void* stream);
+int stil_proto_commit(float* prototypes, float* prototypes_sum, float* prototypes_count_sum,
+                      int* bad_count_dev, int K, int Dp, void* stream);
+
+/* ---- flat-slab EMA teacher update and Adam: STiLModel.py:154-168, 563-570 */
+int stil_ema_update(float* ema, const float* model, long n, double momentum, void* stream);
+int stil_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                   const int* chunk2tensor, int* steps, const unsigned char* active, int n_tensors, long n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

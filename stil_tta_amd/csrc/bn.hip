@@ -1,0 +1,373 @@
+// NHWC BatchNorm (train statistics / apply / backward), eval-mode affine folding, 3x3-s2 max-pool
+// and the stem im2col.  HBM-bound kernels: 16-byte coalesced accesses along the channel axis,
+// per-thread register accumulation, LDS cross-row reduction, fixed-order (deterministic) finals.
+// Replaces nn.BatchNorm2d / nn.ReLU / residual add / nn.MaxPool2d of models/resnets.py:112-132,248-252.
+#include "common.h"
+
+static inline int pick_ctile(int C) {
+  if (C % 256 == 0) return 256;
+  if (C % 128 == 0) return 128;
+  if (C % 64 == 0) return 64;
+  return 0;
+}
+
+// ---- statistics: shifted one-pass sums  S1 = sum(x - K), S2 = sum((x - K)^2),  K = x[0, c]
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, float* __restrict__ part,
+                                                                int M, int C, int ctile, int rows_per_chunk) {
+  __shared__ float sh[2 * 1024];
+  const int tpr = ctile >> 2, rpb = 256 / tpr;
+  const int tc = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+  const int c = blockIdx.x * ctile + tc * 4;
+  const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
+  const float4 K = *reinterpret_cast<const float4*>(x + c);
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  for (int m = m0 + rl; m < m1; m += rpb) {
+    float4 v = *reinterpret_cast<const float4*>(x + (long)m * C + c);
+    float d;
+    d = v.x - K.x; s1.x += d; s2.x += d * d;
+    d = v.y - K.y; s1.y += d; s2.y += d * d;
+    d = v.z - K.z; s1.z += d; s2.z += d * d;
+    d = v.w - K.w; s1.w += d; s2.w += d * d;
+  }
+  float* a = sh + rl * ctile + tc * 4;
+  float* b = sh + 1024 + rl * ctile + tc * 4;
+  a[0] = s1.x; a[1] = s1.y; a[2] = s1.z; a[3] = s1.w;
+  b[0] = s2.x; b[1] = s2.y; b[2] = s2.z; b[3] = s2.w;
+  __syncthreads();
+  if (threadIdx.x < ctile) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int r = 0; r < rpb; ++r) { t1 += sh[r * ctile + threadIdx.x]; t2 += sh[1024 + r * ctile + threadIdx.x]; }
+    const int cc = blockIdx.x * ctile + threadIdx.x;
+    const int nch = gridDim.y;
+    part[(long)blockIdx.y * C + cc] = t1;
+    part[(long)(nch + blockIdx.y) * C + cc] = t2;
+  }
+}
+
+// stats[0]=mean, [1]=rstd, [2]=a=gamma*rstd, [3]=b=beta-mean*a ; updates running stats (momentum, unbiased var)
+__global__ void bn_stats_final_kernel(const float* __restrict__ x, const float* __restrict__ part, int nch, int M, int C,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      float* __restrict__ rmean, float* __restrict__ rvar, long long* nbt,
+                                      float* __restrict__ stats, float eps, float momentum) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;
+  if (c >= C) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = 0; i < nch; ++i) { s1 += part[(long)i * C + c]; s2 += part[(long)(nch + i) * C + c]; }
+  const float invM = 1.f / (float)M;
+  const float d = s1 * invM;
+  const float mean = x[c] + d;
+  float var = s2 * invM - d * d;
+  var = fmaxf(var, 0.f);
+  const float rstd = 1.f / sqrtf(var + eps);
+  const float a = gamma[c] * rstd;
+  stats[c] = mean; stats[C + c] = rstd; stats[2 * C + c] = a; stats[3 * C + c] = beta[c] - mean * a;
+  if (rmean) {
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+    float unb = (M > 1) ? var * ((float)M / (float)(M - 1)) : var;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+  }
+}
+
+// eval mode: a = gamma / sqrt(running_var + eps), b = beta - running_mean * a   (folded into the conv epilogue)
+__global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                      float* __restrict__ ab, int C, float eps) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = gamma[c] / sqrtf(rvar[c] + eps);
+  ab[c] = a; ab[C + c] = beta[c] - rmean[c] * a;
+}
+
+// z = relu?( x*a + b (+ resid) )
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                        const float* __restrict__ resid, float* __restrict__ z,
+                                                        long total4, int C, int relu) {
+  const float* A = stats + 2 * C;
+  const float* B = stats + 3 * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)((i * 4) % C);
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 a = *reinterpret_cast<const float4*>(A + c);
+    const float4 b = *reinterpret_cast<const float4*>(B + c);
+    v.x = v.x * a.x + b.x; v.y = v.y * a.y + b.y; v.z = v.z * a.z + b.z; v.w = v.w * a.w + b.w;
+    if (resid) {
+      const float4 r = reinterpret_cast<const float4*>(resid)[i];
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    reinterpret_cast<float4*>(z)[i] = v;
+  }
+}
+
+// ---- backward pass 1: per-channel sums of g and g*xhat, g = dz * (z > 0) if relu.  Optionally stores g.
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dz, const float* __restrict__ z,
+                                                              const float* __restrict__ x, const float* __restrict__ stats,
+                                                              float* __restrict__ gout, float* __restrict__ part, int M,
+                                                              int C, int ctile, int rows_per_chunk, int relu) {
+  __shared__ float sh[2 * 1024];
+  const int tpr = ctile >> 2, rpb = 256 / tpr;
+  const int tc = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+  const int c = blockIdx.x * ctile + tc * 4;
+  const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
+  const float4 mu = *reinterpret_cast<const float4*>(stats + c);
+  const float4 rs = *reinterpret_cast<const float4*>(stats + C + c);
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  for (int m = m0 + rl; m < m1; m += rpb) {
+    const long o = (long)m * C + c;
+    float4 g = *reinterpret_cast<const float4*>(dz + o);
+    if (relu) {
+      const float4 zz = *reinterpret_cast<const float4*>(z + o);
+      g.x = zz.x > 0.f ? g.x : 0.f; g.y = zz.y > 0.f ? g.y : 0.f;
+      g.z = zz.z > 0.f ? g.z : 0.f; g.w = zz.w > 0.f ? g.w : 0.f;
+    }
+    if (gout) *reinterpret_cast<float4*>(gout + o) = g;
+    const float4 v = *reinterpret_cast<const float4*>(x + o);
+    s1.x += g.x; s2.x += g.x * ((v.x - mu.x) * rs.x);
+    s1.y += g.y; s2.y += g.y * ((v.y - mu.y) * rs.y);
+    s1.z += g.z; s2.z += g.z * ((v.z - mu.z) * rs.z);
+    s1.w += g.w; s2.w += g.w * ((v.w - mu.w) * rs.w);
+  }
+  float* a = sh + rl * ctile + tc * 4;
+  float* b = sh + 1024 + rl * ctile + tc * 4;
+  a[0] = s1.x; a[1] = s1.y; a[2] = s1.z; a[3] = s1.w;
+  b[0] = s2.x; b[1] = s2.y; b[2] = s2.z; b[3] = s2.w;
+  __syncthreads();
+  if (threadIdx.x < ctile) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int r = 0; r < rpb; ++r) { t1 += sh[r * ctile + threadIdx.x]; t2 += sh[1024 + r * ctile + threadIdx.x]; }
+    const int cc = blockIdx.x * ctile + threadIdx.x;
+    const int nch = gridDim.y;
+    part[(long)blockIdx.y * C + cc] = t1;
+    part[(long)(nch + blockIdx.y) * C + cc] = t2;
+  }
+}
+
+// dgamma/dbeta (+)= ; coef[0]=gamma*rstd, [1]=dbeta/M, [2]=dgamma/M
+__global__ void bn_bwd_final_kernel(const float* __restrict__ part, int nch, int M, int C,
+                                    const float* __restrict__ gamma, const float* __restrict__ stats,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef,
+                                    int accumulate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = 0; i < nch; ++i) { s1 += part[(long)i * C + c]; s2 += part[(long)(nch + i) * C + c]; }
+  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + s1 : s1;
+  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + s2 : s2;
+  const float invM = 1.f / (float)M;
+  coef[c] = gamma[c] * stats[C + c];
+  coef[C + c] = s1 * invM;
+  coef[2 * C + c] = s2 * invM;
+}
+
+// dx = gamma*rstd * (g - dbeta/M - xhat*dgamma/M)
+__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict__ dz, const float* __restrict__ z,
+                                                         const float* __restrict__ x, const float* __restrict__ stats,
+                                                         const float* __restrict__ coef, float* __restrict__ dx,
+                                                         long total4, int C, int relu) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)((i * 4) % C);
+    float4 g = reinterpret_cast<const float4*>(dz)[i];
+    if (relu) {
+      const float4 zz = reinterpret_cast<const float4*>(z)[i];
+      g.x = zz.x > 0.f ? g.x : 0.f; g.y = zz.y > 0.f ? g.y : 0.f;
+      g.z = zz.z > 0.f ? g.z : 0.f; g.w = zz.w > 0.f ? g.w : 0.f;
+    }
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 mu = *reinterpret_cast<const float4*>(stats + c);
+    const float4 rs = *reinterpret_cast<const float4*>(stats + C + c);
+    const float4 k1 = *reinterpret_cast<const float4*>(coef + c);
+    const float4 k2 = *reinterpret_cast<const float4*>(coef + C + c);
+    const float4 k3 = *reinterpret_cast<const float4*>(coef + 2 * C + c);
+    float4 o;
+    o.x = k1.x * (g.x - k2.x - (v.x - mu.x) * rs.x * k3.x);
+    o.y = k1.y * (g.y - k2.y - (v.y - mu.y) * rs.y * k3.y);
+    o.z = k1.z * (g.z - k2.z - (v.z - mu.z) * rs.z * k3.z);
+    o.w = k1.w * (g.w - k2.w - (v.w - mu.w) * rs.w * k3.w);
+    reinterpret_cast<float4*>(dx)[i] = o;
+  }
+}
+
+// ---- max-pool 3x3 s2 p1 (NHWC).  idx = ky*3+kx of the FIRST maximum in scan order (ATen tie rule).
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx,
+                                   int N, int H, int W, int C, int OH, int OW) {
+  long total = (long)N * OH * OW * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    long t = i / C;
+    int ox = (int)(t % OW); t /= OW;
+    int oy = (int)(t % OH);
+    int n = (int)(t / OH);
+    float best = -INFINITY;
+    int bi = 0;
+    for (int ky = 0; ky < 3; ++ky) {
+      int iy = oy * 2 - 1 + ky;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        int ix = ox * 2 - 1 + kx;
+        if (ix < 0 || ix >= W) continue;
+        float v = x[((long)(n * H + iy) * W + ix) * C + c];
+        if (v > best || v != v) { best = v; bi = ky * 3 + kx; }
+      }
+    }
+    y[i] = best;
+    idx[i] = (unsigned char)bi;
+  }
+}
+
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                   float* __restrict__ dx, int N, int H, int W, int C, int OH, int OW) {
+  long total = (long)N * H * W * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    long t = i / C;
+    int ix = (int)(t % W); t /= W;
+    int iy = (int)(t % H);
+    int n = (int)(t / H);
+    float s = 0.f;
+    for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {
+      if (oy < 0 || oy >= OH) continue;
+      int ky = iy - (oy * 2 - 1);
+      if (ky < 0 || ky > 2) continue;
+      for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
+        if (ox < 0 || ox >= OW) continue;
+        int kx = ix - (ox * 2 - 1);
+        if (kx < 0 || kx > 2) continue;
+        long o = ((long)(n * OH + oy) * OW + ox) * C + c;
+        if (idx[o] == ky * 3 + kx) s += dy[o];
+      }
+    }
+    dx[i] = s;
+  }
+}
+
+// ---- stem im2col: NCHW image -> col[M, Kp], k = c*KH*KW + ky*KW + kx (the reference weight order), zero padded
+__global__ void im2col_nchw_kernel(const float* __restrict__ x, float* __restrict__ col, int N, int Cin, int H, int W,
+                                   int OH, int OW, int KH, int KW, int stride, int pad, int Kp) {
+  long total = (long)N * OH * OW * Kp;
+  const int K = Cin * KH * KW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int k = (int)(i % Kp);
+    long m = i / Kp;
+    float v = 0.f;
+    if (k < K) {
+      int ox = (int)(m % OW);
+      long t = m / OW;
+      int oy = (int)(t % OH);
+      int n = (int)(t / OH);
+      int c = k / (KH * KW), r = k - c * KH * KW;
+      int ky = r / KW, kx = r - ky * KW;
+      int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((long)(n * Cin + c) * H + iy) * W + ix];
+    }
+    col[i] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+static inline int bn_chunks(int M, int C, int ctile) {
+  int colblocks = C / ctile;
+  int want = cdiv(1024, colblocks);
+  int maxc = cdiv(M, 64);
+  int n = want < maxc ? want : maxc;
+  return n < 1 ? 1 : n;
+}
+
+extern "C" size_t stil_bn_workspace_bytes(int M, int C) {
+  int ct = pick_ctile(C);
+  if (!ct) return 0;
+  return (size_t)2 * bn_chunks(M, C, ct) * C * sizeof(float);
+}
+
+extern "C" int stil_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
+                                 float* running_var, long long* num_batches_tracked, const float* resid, float* z,
+                                 float* stats, int M, int C, int relu, float eps, float momentum, float* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  STIL_REQUIRE(x && gamma && beta && z && stats && workspace, "stil_bn_train_fwd: null pointer");
+  int ct = pick_ctile(C);
+  STIL_REQUIRE(ct != 0, "stil_bn_train_fwd: C=%d must be a multiple of 64", C);
+  int nch = bn_chunks(M, C, ct);
+  STIL_REQUIRE(workspace_bytes >= (size_t)2 * nch * C * sizeof(float), "stil_bn_train_fwd: workspace too small");
+  int rpc = cdiv(M, nch);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C / ct, nch), dim3(256), 0, s, x, workspace, M, C, ct, rpc);
+  STIL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, x, workspace, nch, M, C, gamma, beta,
+                     running_mean, running_var, num_batches_tracked, stats, eps, momentum);
+  STIL_LAUNCH_CHECK();
+  long total4 = (long)M * C / 4;
+  int grid = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, s, x, stats, resid, z, total4, C, relu);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" int stil_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                                   const float* running_var, float* ab, int C, float eps, void* stream) {
+  STIL_REQUIRE(gamma && beta && running_mean && running_var && ab, "stil_bn_eval_affine: null pointer");
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, gamma, beta,
+                     running_mean, running_var, ab, C, eps);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+// dz: grad wrt the block output; z: that output (relu mask); x: conv output (pre-BN).
+// gout (optional): receives g = dz*(z>0) (the gradient of the residual branch).  coef: [3*C] scratch.
+extern "C" int stil_bn_train_bwd(const float* dz, const float* z, const float* x, const float* gamma,
+                                 const float* stats, float* dx, float* gout, float* dgamma, float* dbeta, float* coef,
+                                 int M, int C, int relu, int accumulate, float* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  STIL_REQUIRE(dz && x && gamma && stats && dx && coef && workspace, "stil_bn_train_bwd: null pointer");
+  STIL_REQUIRE(!relu || z, "stil_bn_train_bwd: relu needs z");
+  int ct = pick_ctile(C);
+  STIL_REQUIRE(ct != 0, "stil_bn_train_bwd: C=%d must be a multiple of 64", C);
+  int nch = bn_chunks(M, C, ct);
+  STIL_REQUIRE(workspace_bytes >= (size_t)2 * nch * C * sizeof(float), "stil_bn_train_bwd: workspace too small");
+  int rpc = cdiv(M, nch);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C / ct, nch), dim3(256), 0, s, dz, z, x, stats, gout, workspace, M, C,
+                     ct, rpc, relu);
+  STIL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, workspace, nch, M, C, gamma, stats, dgamma,
+                     dbeta, coef, accumulate);
+  STIL_LAUNCH_CHECK();
+  long total4 = (long)M * C / 4;
+  int grid = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
+  // if g was materialised, read it (already masked) instead of dz,z
+  hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(grid), dim3(256), 0, s, gout ? gout : dz, z, x, stats, coef, dx, total4, C,
+                     gout ? 0 : relu);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" int stil_maxpool3x3s2_fwd(const float* x, float* y, unsigned char* idx, int N, int H, int W, int C, int OH,
+                                     int OW, void* stream) {
+  STIL_REQUIRE(x && y && idx, "stil_maxpool3x3s2_fwd: null pointer");
+  STIL_REQUIRE(OH == (H + 2 - 3) / 2 + 1 && OW == (W + 2 - 3) / 2 + 1, "stil_maxpool3x3s2_fwd: bad output dims");
+  long total = (long)N * OH * OW * C;
+  int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, idx, N, H, W, C, OH, OW);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" int stil_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, float* dx, int N, int H, int W, int C,
+                                     int OH, int OW, void* stream) {
+  STIL_REQUIRE(dy && idx && dx, "stil_maxpool3x3s2_bwd: null pointer");
+  long total = (long)N * H * W * C;
+  int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, N, H, W, C, OH, OW);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" int stil_im2col_nchw(const float* x, float* col, int N, int Cin, int H, int W, int OH, int OW, int KH,
+                                int KW, int stride, int pad, int Kp, void* stream) {
+  STIL_REQUIRE(x && col && Kp >= Cin * KH * KW, "stil_im2col_nchw: null pointer or Kp too small");
+  long total = (long)N * OH * OW * Kp;
+  int grid = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
+  hipLaunchKernelGGL(im2col_nchw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, col, N, Cin, H, W, OH, OW,
+                     KH, KW, stride, pad, Kp);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}

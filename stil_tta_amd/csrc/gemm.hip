@@ -1,0 +1,478 @@
+// fp32-exact MFMA GEMM family for gfx950 (v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD).
+//
+//  * gemm_nt_kernel  : C[M,N] = epilogue( alpha * Agather[M,K] . W[N,K]^T )
+//        Agather is either a plain row-major matrix or an implicit-im2col gather of an
+//        NHWC tensor (forward conv, or the transposed-conv gather used for dgrad).  It
+//        replaces the ATen ops the reference issues for nn.Conv2d / nn.Linear forward and
+//        their input-gradients (models/resnets.py:112-132, models/Transformer.py:27-33,63-88).
+//  * gemm_tn_kernel  : P[z][N,K] = sum_m dY[m,N] . Xgather[m,K]  (weight gradients, split over m)
+//  * wgrad_reduce    : dW = (+=) sum_z P[z], written in the reference's (Cout,Cin,KH,KW) layout
+//  * colsum          : bias gradients
+//
+// Tiling: 256 threads = 4 waves (2x2); each wave owns TMxTN 32x32 accumulators; BK = 16.
+// LDS rows are padded to 20 floats: ds_read_b128 of 4 consecutive k is then conflict-free
+// for every 16-lane group (i*20 mod 64 distinct multiples of 4), and one b128 read feeds
+// four MFMA k-steps.  The k order inside a 8-wide group is permuted identically for A and B.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvGeom {
+  int H, W, C;    // source NHWC dims (rows of the source have stride ld)
+  int OH, OW;     // the GEMM row index m enumerates (n, oy, ox)
+  int KH, KW, stride, pad;
+  int mode;       // 0: forward gather  iy = oy*stride - pad + ky ; 1: dgrad gather  iy = (oy + pad - ky)/stride
+};
+
+struct GemmNTArgs {
+  const float* A;
+  const float* Bw;
+  float* C;
+  int M, N, K;
+  int lda, ldb, ldc;
+  ConvGeom g;
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  const float* resid;
+  int ldr;
+  float* pre;
+  int act;  // 0 none, 1 relu, 2 gelu
+  float alpha;
+  int vecA, vecB;  // 1: 16-byte aligned rows -> float4 loads
+};
+
+__device__ __forceinline__ float4 ld4_guard(const float* p, int nvalid, int vec) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (nvalid >= 4 && vec) {
+    v = *reinterpret_cast<const float4*>(p);
+  } else {
+    if (nvalid > 0) v.x = p[0];
+    if (nvalid > 1) v.y = p[1];
+    if (nvalid > 2) v.z = p[2];
+    if (nvalid > 3) v.w = p[3];
+  }
+  return v;
+}
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  // blocks b and b+8 share an XCD (speed only): give each XCD a contiguous range of logical tiles.
+  int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
+  constexpr int BM = 64 * TM, BN = 64 * TN, BK = 16, LS = 20;
+  constexpr int RA = BM / 64, RB = BN / 64;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LS];
+  float* As = lds;
+  float* Bs = lds + 2 * BM * LS;
+
+  const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
+  const int wg = xcd_remap(blockIdx.x, nbm * nbn);
+  const int tm = wg / nbn, tn = wg - tm * nbn;
+  const int tid = threadIdx.x, kq = tid & 3, r0 = tid >> 2;
+  const ConvGeom g = p.g;
+
+  int a_n[RA], a_oy[RA], a_ox[RA];
+  bool a_ok[RA];
+#pragma unroll
+  for (int i = 0; i < RA; ++i) {
+    int m = tm * BM + r0 + 64 * i;
+    a_ok[i] = m < p.M;
+    int mm = a_ok[i] ? m : 0;
+    int ohw = g.OH * g.OW;
+    int n = mm / ohw, rem = mm - n * ohw;
+    int oy = rem / g.OW;
+    a_n[i] = n; a_oy[i] = oy; a_ox[i] = rem - oy * g.OW;
+  }
+  const float* b_ptr[RB];
+  bool b_ok[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+    int n = tn * BN + r0 + 64 * i;
+    b_ok[i] = n < p.N;
+    b_ptr[i] = p.Bw + (long)(b_ok[i] ? n : 0) * p.ldb + kq * 4;
+  }
+
+  float4 ra[RA], rb[RB];
+  auto gload = [&](int kt) {
+    const int k0 = kt * BK;
+    const int tap = k0 / g.C, c0 = k0 - tap * g.C;
+    const int ky = tap / g.KW, kx = tap - ky * g.KW;
+    const int nval = p.K - (k0 + kq * 4);
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      int iy, ix;
+      bool ok = a_ok[i];
+      if (g.mode == 0) {
+        iy = a_oy[i] * g.stride - g.pad + ky;
+        ix = a_ox[i] * g.stride - g.pad + kx;
+      } else {
+        int ty = a_oy[i] + g.pad - ky, tx = a_ox[i] + g.pad - kx;
+        ok = ok && ty >= 0 && tx >= 0;
+        iy = ty / g.stride; ix = tx / g.stride;
+        ok = ok && (iy * g.stride == ty) && (ix * g.stride == tx);
+      }
+      ok = ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+      const float* src = p.A + ((long)(a_n[i] * g.H + iy) * g.W + ix) * p.lda + c0 + kq * 4;
+      ra[i] = ok ? ld4_guard(src, nval, p.vecA) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+      rb[i] = b_ok[i] ? ld4_guard(b_ptr[i] + k0, nval, p.vecB) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i)
+      *reinterpret_cast<float4*>(&As[buf * BM * LS + (r0 + 64 * i) * LS + kq * 4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+      *reinterpret_cast<float4*>(&Bs[buf * BN * LS + (r0 + 64 * i) * LS + kq * 4]) = rb[i];
+  };
+
+  const int w = tid >> 6, wm = w >> 1, wn = w & 1, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (p.K + BK - 1) / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    const float* Ab = As + buf * BM * LS + (wm * TM * 32 + li) * LS + lh * 4;
+    const float* Bb = Bs + buf * BN * LS + (wn * TN * 32 + li) * LS + lh * 4;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LS + t * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LS + t * 8);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: C/D map of 32x32 tiles: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = tn * BN + wn * TN * 32 + j * 32 + li;
+    if (col >= p.N) continue;
+    const float bia = p.bias ? p.bias[col] : 0.f;
+    const float sc = p.scale ? p.scale[col] : 1.f;
+    const float sh = p.shift ? p.shift[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = tm * BM + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row >= p.M) continue;
+        float v = acc[i][j][r] * p.alpha;
+        v = v * sc + sh + bia;
+        if (p.resid) v += p.resid[(long)row * p.ldr + col];
+        if (p.pre) p.pre[(long)row * p.ldc + col] = v;
+        if (p.act == 1) v = fmaxf(v, 0.f);
+        else if (p.act == 2) v = gelu_f(v);
+        p.C[(long)row * p.ldc + col] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+struct GemmTNArgs {
+  const float* Y;  // [M, N], row stride ldy
+  const float* X;  // gather source (NHWC, row stride ldx) -- geometry g, mode 0
+  float* P;        // [splits][N][K]
+  int M, N, K;
+  int ldy, ldx;
+  ConvGeom g;
+  int m_per_split;
+  int vecY, vecX;
+};
+
+template <int TNn, int TK>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p) {
+  constexpr int BN = 64 * TNn, BKo = 64 * TK, BMr = 16;
+  constexpr int Y4 = BN / 4, X4 = BKo / 4;            // float4 per row
+  constexpr int YR = 256 / Y4, XR = 256 / X4;         // rows per pass
+  constexpr int YP = BMr / YR, XP = BMr / XR;         // passes
+  __shared__ __attribute__((aligned(16))) float lds[2 * BMr * (BN + BKo)];
+  float* Ys = lds;
+  float* Xs = lds + 2 * BMr * BN;
+
+  const int nbk = (p.K + BKo - 1) / BKo, nbn = (p.N + BN - 1) / BN;
+  const int wg = xcd_remap(blockIdx.x, nbn * nbk);
+  const int tn = wg / nbk, tk = wg - tn * nbk;
+  const int z = blockIdx.z;
+  const int m_begin = z * p.m_per_split;
+  const int m_end = min(p.M, m_begin + p.m_per_split);
+  const int tid = threadIdx.x;
+  const ConvGeom g = p.g;
+
+  const int yc = tid % Y4, yr = tid / Y4;
+  const int xc = tid % X4, xr = tid / X4;
+  const int ycol = tn * BN + yc * 4;
+  const int xk = tk * BKo + xc * 4;           // this thread's k (fixed over the loop)
+  const int xtap = xk / g.C, xcch = xk - xtap * g.C;
+  const int xky = xtap / g.KW, xkx = xtap - xky * g.KW;
+  const int ohw = g.OH * g.OW;
+
+  float4 ry[YP], rx[XP];
+  auto gload = [&](int mt) {
+    const int m0 = m_begin + mt * BMr;
+#pragma unroll
+    for (int i = 0; i < YP; ++i) {
+      int m = m0 + yr + YR * i;
+      ry[i] = (m < m_end) ? ld4_guard(p.Y + (long)m * p.ldy + ycol, p.N - ycol, p.vecY) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      int m = m0 + xr + XR * i;
+      bool ok = m < m_end && xk < p.K;
+      int mm = ok ? m : 0;
+      int n = mm / ohw, rem = mm - n * ohw;
+      int oy = rem / g.OW, ox = rem - oy * g.OW;
+      int iy = oy * g.stride - g.pad + xky, ix = ox * g.stride - g.pad + xkx;
+      ok = ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+      const float* src = p.X + ((long)(n * g.H + iy) * g.W + ix) * p.ldx + xcch;
+      rx[i] = ok ? ld4_guard(src, p.K - xk, p.vecX) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < YP; ++i)
+      *reinterpret_cast<float4*>(&Ys[buf * BMr * BN + (yr + YR * i) * BN + yc * 4]) = ry[i];
+#pragma unroll
+    for (int i = 0; i < XP; ++i)
+      *reinterpret_cast<float4*>(&Xs[buf * BMr * BKo + (xr + XR * i) * BKo + xc * 4]) = rx[i];
+  };
+
+  const int w = tid >> 6, wn = w >> 1, wk = w & 1, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  f32x16 acc[TNn][TK];
+#pragma unroll
+  for (int i = 0; i < TNn; ++i)
+#pragma unroll
+    for (int j = 0; j < TK; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nm = (m_end - m_begin + BMr - 1) / BMr;
+  if (nm > 0) {
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int mt = 0; mt < nm; ++mt) {
+    const int buf = mt & 1;
+    if (mt + 1 < nm) gload(mt + 1);
+    const float* Yb = Ys + buf * BMr * BN + wn * TNn * 32 + li;
+    const float* Xb = Xs + buf * BMr * BKo + wk * TK * 32 + li;
+#pragma unroll
+    for (int s = 0; s < BMr / 2; ++s) {
+      float a[TNn], b[TK];
+#pragma unroll
+      for (int i = 0; i < TNn; ++i) a[i] = Yb[(2 * s + lh) * BN + i * 32];
+#pragma unroll
+      for (int j = 0; j < TK; ++j) b[j] = Xb[(2 * s + lh) * BKo + j * 32];
+#pragma unroll
+      for (int i = 0; i < TNn; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (mt + 1 < nm) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  float* P = p.P + (long)z * p.N * p.K;
+#pragma unroll
+  for (int j = 0; j < TK; ++j) {
+    const int col = tk * BKo + wk * TK * 32 + j * 32 + li;
+    if (col >= p.K) continue;
+#pragma unroll
+    for (int i = 0; i < TNn; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = tn * BN + wn * TNn * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < p.N) P[(long)row * p.K + col] = acc[i][j][r];
+      }
+  }
+}
+
+// dW[n, dst(k)] (+)= sum_z P[z][n][k];  conv: k = tap*Cin + c  ->  dst = c*taps + tap  (Cout,Cin,KH,KW)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ P, float* __restrict__ dW, int splits, int N, int K,
+                                    int Cin, int taps, int Kdst, int accumulate) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)N * K;
+  if (idx >= total) return;
+  int n = (int)(idx / K), k = (int)(idx - (long)n * K);
+  float s = 0.f;
+  for (int zz = 0; zz < splits; ++zz) s += P[(long)zz * total + idx];
+  int dst;
+  if (taps > 1) {
+    int tap = k / Cin, c = k - tap * Cin;
+    dst = c * taps + tap;
+  } else {
+    dst = k;
+  }
+  if (dst >= Kdst) return;
+  long o = (long)n * Kdst + dst;
+  dW[o] = accumulate ? dW[o] + s : s;
+}
+
+// ---------------------------------------------------------------------------------------
+// column sums  out[c] (+)= sum_m X[m, c]   (bias grads).  Stage 1: per row-chunk partials.
+__global__ void colsum_partial_kernel(const float* __restrict__ X, float* __restrict__ part, int M, int N, int ld,
+                                      int rows_per_chunk) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
+  float s = 0.f;
+  for (int m = m0; m < m1; ++m) s += X[(long)m * ld + c];
+  part[(long)blockIdx.y * N + c] = s;
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nchunks, int N,
+                                    int accumulate, float scale) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  float s = 0.f;
+  for (int i = 0; i < nchunks; ++i) s += part[(long)i * N + c];
+  s *= scale;
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+// ---------------------------------------------------------------------------------------
+static int check_geom(const ConvGeom& g, int vec_required) {
+  if (g.KH * g.KW > 1 && (g.C % 16) != 0) {
+    stil_set_error("implicit-GEMM conv needs Cin %% 16 == 0 (got %d)", g.C);
+    return STIL_EUNSUPPORTED;
+  }
+  (void)vec_required;
+  return STIL_OK;
+}
+
+static inline int is_vec(const void* p, int ld) { return (((uintptr_t)p) % 16 == 0) && (ld % 4 == 0); }
+
+// which tile variant stil_gemm_nt launches for an [M,N] output: 22 = 128x128, 21 = 128x64, 11 = 64x64 block tile
+extern "C" int stil_gemm_nt_variant(int M, int N) {
+  if (N <= 64) return M <= 4096 ? 11 : 21;
+  if ((long)cdiv(M, 128) * cdiv(N, 128) < 128) return 11;
+  return 22;
+}
+
+extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                            int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad,
+                            int mode, const float* bias, const float* scale, const float* shift,
+                            const float* resid, int ldr, float* pre, int act, float alpha, void* stream) {
+  STIL_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0, "stil_gemm_nt: null pointer or empty shape (M=%d N=%d K=%d)", M, N, K);
+  STIL_REQUIRE(KH * KW * srcC == K, "stil_gemm_nt: K=%d != KH*KW*C=%d", K, KH * KW * srcC);
+  STIL_REQUIRE(M % (OH * OW) == 0, "stil_gemm_nt: M=%d not a multiple of OH*OW=%d", M, OH * OW);
+  GemmNTArgs p;
+  p.A = A; p.Bw = W; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.g = ConvGeom{srcH, srcW, srcC, OH, OW, KH, KW, stride, pad, mode};
+  p.bias = bias; p.scale = scale; p.shift = shift; p.resid = resid; p.ldr = ldr; p.pre = pre; p.act = act;
+  p.alpha = alpha;
+  p.vecA = is_vec(A, lda) && (srcC % 4 == 0);
+  p.vecB = is_vec(W, ldb);
+  int rc = check_geom(p.g, 0);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int variant = stil_gemm_nt_variant(M, N);
+  if (variant == 11) {
+    dim3 grid(cdiv(M, 64) * cdiv(N, 64));
+    hipLaunchKernelGGL((gemm_nt_kernel<1, 1>), grid, dim3(256), 0, s, p);
+  } else if (variant == 21) {
+    dim3 grid(cdiv(M, 128) * cdiv(N, 64));
+    hipLaunchKernelGGL((gemm_nt_kernel<2, 1>), grid, dim3(256), 0, s, p);
+  } else {
+    dim3 grid(cdiv(M, 128) * cdiv(N, 128));
+    hipLaunchKernelGGL((gemm_nt_kernel<2, 2>), grid, dim3(256), 0, s, p);
+  }
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+static int wgrad_splits(int M, int N, int K) {
+  int tiles = cdiv(N, N <= 64 ? 64 : 128) * cdiv(K, 128);
+  int want = cdiv(768, tiles);
+  int maxs = M / 256 > 0 ? M / 256 : 1;
+  int s = want < maxs ? want : maxs;
+  if (s < 1) s = 1;
+  if (s > 256) s = 256;
+  return s;
+}
+
+extern "C" size_t stil_wgrad_workspace_bytes(int M, int N, int K) {
+  return (size_t)wgrad_splits(M, N, K) * N * K * sizeof(float);
+}
+
+// dW (+)= dY^T . Xgather ; dW laid out [N, Kdst] (taps==1) or (N, Cin, KH, KW) (taps>1)
+extern "C" int stil_wgrad_tn(const float* dY, const float* X, float* dW, int M, int N, int K, int ldy, int ldx,
+                             int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad,
+                             int Kdst, int accumulate, float* workspace, size_t workspace_bytes, void* stream) {
+  STIL_REQUIRE(dY && X && dW && workspace, "stil_wgrad_tn: null pointer");
+  STIL_REQUIRE(KH * KW * srcC == K, "stil_wgrad_tn: K=%d != KH*KW*C=%d", K, KH * KW * srcC);
+  STIL_REQUIRE(M % (OH * OW) == 0, "stil_wgrad_tn: M=%d not a multiple of OH*OW", M);
+  STIL_REQUIRE(srcC % 4 == 0 || KH * KW == 1, "stil_wgrad_tn: conv needs Cin %% 4 == 0");
+  int splits = wgrad_splits(M, N, K);
+  STIL_REQUIRE(workspace_bytes >= (size_t)splits * N * K * sizeof(float), "stil_wgrad_tn: workspace too small");
+  GemmTNArgs p;
+  p.Y = dY; p.X = X; p.P = workspace; p.M = M; p.N = N; p.K = K; p.ldy = ldy; p.ldx = ldx;
+  p.g = ConvGeom{srcH, srcW, srcC, OH, OW, KH, KW, stride, pad, 0};
+  int mps = cdiv(M, splits);
+  mps = ((mps + 15) / 16) * 16;
+  p.m_per_split = mps;
+  p.vecY = is_vec(dY, ldy);
+  p.vecX = is_vec(X, ldx) && (srcC % 4 == 0);
+  hipStream_t s = (hipStream_t)stream;
+  if (N <= 64) {
+    dim3 grid(cdiv(N, 64) * cdiv(K, 128), 1, splits);
+    hipLaunchKernelGGL((gemm_tn_kernel<1, 2>), grid, dim3(256), 0, s, p);
+  } else {
+    dim3 grid(cdiv(N, 128) * cdiv(K, 128), 1, splits);
+    hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), grid, dim3(256), 0, s, p);
+  }
+  STIL_LAUNCH_CHECK();
+  long total = (long)N * K;
+  int taps = KH * KW;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, workspace, dW, splits, N, K, srcC,
+                     taps, Kdst, accumulate);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" size_t stil_colsum_workspace_bytes(int M, int N) {
+  int rpc = 512;
+  return (size_t)cdiv(M, rpc) * N * sizeof(float);
+}
+
+extern "C" int stil_colsum(const float* X, float* out, int M, int N, int ld, int accumulate, float scale,
+                           float* workspace, size_t workspace_bytes, void* stream) {
+  STIL_REQUIRE(X && out && workspace && M > 0 && N > 0, "stil_colsum: null pointer or empty shape");
+  int rpc = 512, nch = cdiv(M, rpc);
+  STIL_REQUIRE(workspace_bytes >= (size_t)nch * N * sizeof(float), "stil_colsum: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), nch), dim3(64), 0, s, X, workspace, M, N, ld, rpc);
+  STIL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 64)), dim3(64), 0, s, workspace, out, nch, N, accumulate, scale);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}

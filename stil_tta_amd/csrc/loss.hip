@@ -1,0 +1,488 @@
+// Loss tail of STiLModel.training_step as fused row kernels (one block per sample row,
+// wave-shuffle + LDS reductions, fixed-order sums => bit-stable across runs):
+//   hard / soft-target cross-entropy      STiLModel.py:284,301-303
+//   CGPL case partition + PGLS smoothing  STiLModel.py:259-299
+//   CLIP (InfoNCE) LSE + dZ               utils/clip_loss.py:27-39
+//   CLUBMean closed form                  models/Disentangle/utils/club.py:107-130
+//   PrototypeLoss                         utils/prototype_loss.py:24-40
+//   prototype class sums                  STiLModel.py:199-226
+#include "common.h"
+
+// ---------------------------------------------------------------- cross entropy
+// hard labels: row_loss[r] = lse - z[y];  dlogits[r,k] = (softmax - onehot) * inv_rows
+__global__ __launch_bounds__(256) void ce_hard_kernel(const float* __restrict__ z, int ld, const long long* __restrict__ y,
+                                                       float* __restrict__ row_loss, float* __restrict__ dz, int ldd,
+                                                       int K, float inv_rows) {
+  __shared__ float red[16];
+  const int r = blockIdx.x;
+  const float* zr = z + (long)r * ld;
+  float m = -INFINITY;
+  for (int k = threadIdx.x; k < K; k += 256) m = fmaxf(m, zr[k]);
+  m = block_max(m, red);
+  float s = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) s += expf(zr[k] - m);
+  s = block_sum(s, red);
+  const float lse = m + logf(s);
+  const int yy = (int)y[r];
+  if (threadIdx.x == 0) row_loss[r] = lse - zr[yy];
+  if (dz)
+    for (int k = threadIdx.x; k < K; k += 256)
+      dz[(long)r * ldd + k] = (expf(zr[k] - lse) - (k == yy ? 1.f : 0.f)) * inv_rows;
+}
+
+// probability targets with a per-row weight w[r]:
+//   row_loss[r] = w * (-(sum_k q_k * (z_k - lse)));  dz = w * inv_rows * (softmax * sum(q) - q)
+__global__ __launch_bounds__(256) void ce_soft_kernel(const float* __restrict__ z, int ld, const float* __restrict__ q,
+                                                       int ldq, const float* __restrict__ w, float* __restrict__ row_loss,
+                                                       float* __restrict__ dz, int ldd, int K, float inv_rows) {
+  __shared__ float red[16];
+  const int r = blockIdx.x;
+  const float* zr = z + (long)r * ld;
+  const float* qr = q + (long)r * ldq;
+  float m = -INFINITY;
+  for (int k = threadIdx.x; k < K; k += 256) m = fmaxf(m, zr[k]);
+  m = block_max(m, red);
+  float s = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) s += expf(zr[k] - m);
+  s = block_sum(s, red);
+  const float lse = m + logf(s);
+  float a = 0.f, qs = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) { a += qr[k] * (zr[k] - lse); qs += qr[k]; }
+  a = block_sum(a, red);
+  qs = block_sum(qs, red);
+  const float wr = w ? w[r] : 1.f;
+  if (threadIdx.x == 0) row_loss[r] = -a * wr;
+  if (dz)
+    for (int k = threadIdx.x; k < K; k += 256)
+      dz[(long)r * ldd + k] = wr * inv_rows * (expf(zr[k] - lse) * qs - qr[k]);
+}
+
+// out[0] (+)= scale * sum_i x[i]   single block, fixed order
+__global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict__ x, int n, float scale,
+                                                          float* __restrict__ out, int accumulate) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += x[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + s * scale;
+}
+
+// out = x * (*g) * c
+__global__ void scale_dev_kernel(const float* __restrict__ x, const float* __restrict__ g, float c,
+                                 float* __restrict__ out, long n) {
+  const float s = g[0] * c;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = x[i] * s;
+}
+
+// ---------------------------------------------------------------- F.normalize(dim=1), eps 1e-12
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          float* __restrict__ nrm, int R, int D) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const float* xr = x + (long)r * D;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) s += xr[i] * xr[i];
+  const float n = fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+  for (int i = lane; i < D; i += 64) y[(long)r * D + i] = xr[i] / n;
+  if (lane == 0) nrm[r] = n;
+}
+// dx = (g - y * (y . g)) / n
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                          const float* __restrict__ nrm, float* __restrict__ dx, int R,
+                                                          int D) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const float* gr = g + (long)r * D;
+  const float* yr = y + (long)r * D;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) s += gr[i] * yr[i];
+  s = wave_sum(s);
+  const float inv = 1.f / nrm[r];
+  for (int i = lane; i < D; i += 64) dx[(long)r * D + i] = (gr[i] - yr[i] * s) * inv;
+}
+
+// ---------------------------------------------------------------- CLIP: row / column log-sum-exp of Z [B,B]
+__global__ __launch_bounds__(256) void lse_rows_kernel(const float* __restrict__ Z, float* __restrict__ lse, int R, int C) {
+  __shared__ float red[16];
+  const float* zr = Z + (long)blockIdx.x * C;
+  float m = -INFINITY;
+  for (int k = threadIdx.x; k < C; k += 256) m = fmaxf(m, zr[k]);
+  m = block_max(m, red);
+  float s = 0.f;
+  for (int k = threadIdx.x; k < C; k += 256) s += expf(zr[k] - m);
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) lse[blockIdx.x] = m + logf(s);
+}
+__global__ void lse_cols_kernel(const float* __restrict__ Z, float* __restrict__ lse, int R, int C) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float m = -INFINITY;
+  for (int r = 0; r < R; ++r) m = fmaxf(m, Z[(long)r * C + c]);
+  float s = 0.f;
+  for (int r = 0; r < R; ++r) s += expf(Z[(long)r * C + c] - m);
+  lse[c] = m + logf(s);
+}
+// row_term[i] = lam0*(lse_r[i]-Z[i][i]) + lam1*(lse_c[i]-Z[i][i])
+__global__ void clip_terms_kernel(const float* __restrict__ Z, const float* __restrict__ lse_r,
+                                  const float* __restrict__ lse_c, float* __restrict__ terms, int B, float lam0,
+                                  float lam1) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  float d = Z[(long)i * B + i];
+  terms[i] = lam0 * (lse_r[i] - d) + lam1 * (lse_c[i] - d);
+}
+// dZ[r,c] = g * ( lam0/B (exp(z-lse_r[r]) - I) + lam1/B (exp(z-lse_c[c]) - I) )
+__global__ void clip_dz_kernel(const float* __restrict__ Z, const float* __restrict__ lse_r,
+                               const float* __restrict__ lse_c, const float* __restrict__ g, float* __restrict__ dZ,
+                               int B, float lam0, float lam1) {
+  long n = (long)B * B;
+  const float gg = g[0] / (float)B;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int r = (int)(i / B), c = (int)(i - (long)r * B);
+    float z = Z[i], e = (r == c) ? 1.f : 0.f;
+    dZ[i] = gg * (lam0 * (expf(z - lse_r[r]) - e) + lam1 * (expf(z - lse_c[c]) - e));
+  }
+}
+
+// ---------------------------------------------------------------- CLUB (closed form, centred)
+// t[i] = sum_d (y-ybar)^2 + (ybar-mu)^2 - (mu-y)^2 ;  e[i] = sum_d (mu-y)^2
+__global__ __launch_bounds__(256) void club_rows_kernel(const float* __restrict__ mu, const float* __restrict__ y,
+                                                         const float* __restrict__ ybar, float* __restrict__ t,
+                                                         float* __restrict__ e, int R, int D) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= R) return;
+  float a = 0.f, b = 0.f;
+  for (int i = lane; i < D; i += 64) {
+    float m = mu[(long)r * D + i], yy = y[(long)r * D + i], yb = ybar[i];
+    float d0 = yy - yb, d1 = yb - m, d2 = m - yy;
+    a += d0 * d0 + d1 * d1 - d2 * d2;
+    b += d2 * d2;
+  }
+  a = wave_sum(a); b = wave_sum(b);
+  if (lane == 0) { t[r] = a; e[r] = b; }
+}
+// dmu = gc (y - ybar)/B + ge 2(mu-y)/B ;  dy = gc (mu - mubar)/B - ge 2(mu-y)/B
+__global__ void club_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ y,
+                                const float* __restrict__ ybar, const float* __restrict__ mubar,
+                                const float* __restrict__ gc, const float* __restrict__ ge, float* __restrict__ dmu,
+                                float* __restrict__ dy, int R, int D) {
+  long n = (long)R * D;
+  const float c = gc[0] / (float)R, e2 = 2.f * ge[0] / (float)R;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int d = (int)(i % D);
+    float m = mu[i], yy = y[i];
+    dmu[i] = c * (yy - ybar[d]) + e2 * (m - yy);
+    dy[i] = c * (m - mubar[d]) - e2 * (m - yy);
+  }
+}
+
+// ---------------------------------------------------------------- CGPL + PGLS (teacher side, no grad)
+struct CgplArgs {
+  const float* zm; const float* zi; const float* zt; int ldz;   // teacher logits of the unlabelled rows
+  const float* feat; int Dp;                                      // teacher multimodal embedding (normalised)
+  const float* protos;                                            // [K, Dp]
+  const unsigned char* mask_random;                               // [Bu]
+  float* pseudo_label;   // [Bu,K]  r*q0 + (1-r)*tp
+  float* pseudo_orig;    // [Bu,K]  q0 (optional)
+  float* prediction;     // [Bu,K]  r*softmax(zm) + (1-r)*tp, zeroed unless use_pseudo
+  unsigned char* flags;  // [Bu,4]  case id (1..4), mask1, conf, 0
+  int* hard;             // [Bu] argmax of `prediction`
+  float* w3;             // [3,Bu] row weights of the three unlabelled CE terms (m, i, t)
+  int K; float r, T, th; int use_pseudo;
+};
+
+__global__ __launch_bounds__(256) void cgpl_pgls_kernel(CgplArgs p) {
+  extern __shared__ float sh[];  // [3][K] : case logits -> q0 ; zm -> pred ; tl -> tp
+  __shared__ float red[16];
+  __shared__ int ired[3];
+  float* A = sh; float* Bm = sh + p.K; float* Ct = sh + 2 * p.K;
+  const int u = blockIdx.x, K = p.K, tid = threadIdx.x;
+  const float* zm = p.zm + (long)u * p.ldz;
+  const float* zi = p.zi + (long)u * p.ldz;
+  const float* zt = p.zt + (long)u * p.ldz;
+  // first-index argmax of each head (thread 0..2 scan: K is small, keeps ATen's tie rule)
+  if (tid < 3) {
+    const float* z = tid == 0 ? zm : (tid == 1 ? zi : zt);
+    float best = z[0]; int bi = 0;
+    for (int k = 1; k < K; ++k) if (z[k] > best) { best = z[k]; bi = k; }
+    ired[tid] = bi;
+  }
+  __syncthreads();
+  const int a = ired[0], b = ired[1], d = ired[2];
+  int cs;
+  if (a == b && a == d) cs = 1; else if (a == b) cs = 2; else if (a == d) cs = 3; else cs = 4;
+  for (int k = tid; k < K; k += 256) {
+    float m = zm[k], v;
+    if (cs == 1) v = (m + zi[k] + zt[k]) / 3.0f;
+    else if (cs == 2) v = (m + zi[k]) / 2.0f;
+    else if (cs == 3) v = (m + zt[k]) / 2.0f;
+    else v = m;
+    A[k] = v; Bm[k] = m;
+    const float* pr = p.protos + (long)k * p.Dp;
+    const float* f = p.feat + (long)u * p.Dp;
+    float s = 0.f;
+    for (int c = 0; c < p.Dp; ++c) s += f[c] * pr[c];
+    Ct[k] = s / p.T;
+  }
+  __syncthreads();
+  // three softmaxes in place
+  for (int which = 0; which < 3; ++which) {
+    float* v = sh + which * K;
+    float m = -INFINITY;
+    for (int k = tid; k < K; k += 256) m = fmaxf(m, v[k]);
+    m = block_max(m, red);
+    float s = 0.f;
+    for (int k = tid; k < K; k += 256) { float e = expf(v[k] - m); v[k] = e; s += e; }
+    s = block_sum(s, red);
+    for (int k = tid; k < K; k += 256) v[k] = v[k] / s;
+    __syncthreads();
+  }
+  float mx = -INFINITY;
+  for (int k = tid; k < K; k += 256) {
+    float tp = Ct[k];
+    float pl = p.r * A[k] + (1.f - p.r) * tp;
+    float pd = p.r * Bm[k] + (1.f - p.r) * tp;
+    p.pseudo_label[(long)u * K + k] = pl;
+    if (p.pseudo_orig) p.pseudo_orig[(long)u * K + k] = A[k];
+    p.prediction[(long)u * K + k] = p.use_pseudo ? pd : 0.f;
+    Bm[k] = pd;
+    mx = fmaxf(mx, pd);
+  }
+  mx = block_max(mx, red);
+  __syncthreads();
+  if (tid == 0) {
+    int bi = 0;
+    if (p.use_pseudo) { float best = Bm[0]; for (int k = 1; k < K; ++k) if (Bm[k] > best) { best = Bm[k]; bi = k; } }
+    const int mask1 = mx >= p.th ? 1 : 0;
+    const int mr = p.mask_random[u] ? 1 : 0;
+    p.flags[u * 4 + 0] = (unsigned char)cs;
+    p.flags[u * 4 + 1] = (unsigned char)mask1;
+    p.flags[u * 4 + 2] = (unsigned char)((p.use_pseudo && mask1) ? 1 : 0);  // confident for prototypes
+    p.flags[u * 4 + 3] = 0;
+    p.hard[u] = bi;
+    const int Bu = gridDim.x;
+    p.w3[u] = (mask1 && cs == 1) ? 1.f : 0.f;
+    p.w3[Bu + u] = (mask1 && (cs == 1 || cs == 3 || (cs == 4 && mr))) ? 1.f : 0.f;
+    p.w3[2 * Bu + u] = (mask1 && (cs == 1 || cs == 2 || (cs == 4 && !mr))) ? 1.f : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------- PrototypeLoss
+// row_loss = -log(softmax(feat.P^T/T)[hard] + 1e-7) * conf ; dfeat_unit = conf/B * sum_k dz_k P_k / T
+__global__ __launch_bounds__(256) void proto_loss_kernel(const float* __restrict__ feat, const float* __restrict__ protos,
+                                                          const int* __restrict__ hard,
+                                                          const unsigned char* __restrict__ conf,
+                                                          float* __restrict__ row_loss, float* __restrict__ dfeat, int K,
+                                                          int Dp, float T, float inv_rows) {
+  extern __shared__ float sh[];  // [K]
+  __shared__ float red[16];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const float* f = feat + (long)r * Dp;
+  for (int k = tid; k < K; k += 256) {
+    const float* pr = protos + (long)k * Dp;
+    float s = 0.f;
+    for (int c = 0; c < Dp; ++c) s += f[c] * pr[c];
+    sh[k] = s / T;
+  }
+  __syncthreads();
+  float m = -INFINITY;
+  for (int k = tid; k < K; k += 256) m = fmaxf(m, sh[k]);
+  m = block_max(m, red);
+  float s = 0.f;
+  for (int k = tid; k < K; k += 256) { float e = expf(sh[k] - m); sh[k] = e; s += e; }
+  s = block_sum(s, red);
+  for (int k = tid; k < K; k += 256) sh[k] = sh[k] / s;
+  __syncthreads();
+  const int h = hard[r];
+  const float cf = conf[r] ? 1.f : 0.f;
+  const float sh_h = sh[h];
+  if (tid == 0) row_loss[r] = -logf(sh_h + 1e-7f) * cf;
+  if (dfeat) {
+    const float coef = -(sh_h / (sh_h + 1e-7f)) * cf * inv_rows / T;
+    for (int c = tid; c < Dp; c += 256) {
+      float acc = 0.f;
+      for (int k = 0; k < K; ++k) acc += ((k == h ? 1.f : 0.f) - sh[k]) * protos[(long)k * Dp + c];
+      dfeat[(long)r * Dp + c] = coef * acc;
+    }
+  }
+}
+
+// class_sum[k, 0:Dp] = sum_{r: conf, hard==k} wt_r * feat[r] ; class_sum[k, Dp] = sum wt_r  (block per class)
+__global__ void proto_accum_kernel(const float* __restrict__ feat, const int* __restrict__ hard,
+                                   const unsigned char* __restrict__ conf, float* __restrict__ out, int B, int B_l,
+                                   int Dp, float inv_repeat) {
+  const int k = blockIdx.x;
+  for (int c = threadIdx.x; c <= Dp; c += blockDim.x) {
+    float sl = 0.f, su = 0.f;   // the reference sums labelled and unlabelled parts separately, then l/repeat + u
+    for (int r = 0; r < B; ++r) {
+      if (!conf[r] || hard[r] != k) continue;
+      float v = (c < Dp) ? feat[(long)r * Dp + c] : 1.f;
+      if (r < B_l) sl += v; else su += v;
+    }
+    out[(long)k * (Dp + 1) + c] = sl * inv_repeat + su;
+  }
+}
+// prototypes_sum += cs[:, :Dp] ; prototypes_count_sum += cs[:, Dp]
+__global__ void proto_add_kernel(const float* __restrict__ cs, float* __restrict__ psum, float* __restrict__ pcnt, int K,
+                                 int Dp) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K * (Dp + 1)) return;
+  int k = i / (Dp + 1), c = i - k * (Dp + 1);
+  if (c < Dp) psum[(long)k * Dp + c] += cs[i]; else pcnt[k] += cs[i];
+}
+// epoch end: prototypes = sum / count ; zero accumulators ; flag[0] = #classes with count < 1
+__global__ void proto_commit_kernel(float* __restrict__ protos, float* __restrict__ psum, float* __restrict__ pcnt,
+                                    int* __restrict__ bad, int K, int Dp) {
+  int k = blockIdx.x;
+  float cnt = pcnt[k];
+  if (cnt < 1.f) { if (threadIdx.x == 0) atomicAdd(bad, 1); return; }
+  for (int c = threadIdx.x; c < Dp; c += blockDim.x) { protos[(long)k * Dp + c] = psum[(long)k * Dp + c] / cnt; }
+}
+
+// ---------------------------------------------------------------- C ABI
+static inline int ew_grid2(long n) { long g = (n + 255) / 256; return (int)(g < 16384 ? (g < 1 ? 1 : g) : 16384); }
+
+extern "C" int stil_ce_hard(const float* logits, int ld, const long long* labels, float* row_loss, float* dlogits,
+                            int ldd, int rows, int K, float inv_rows, void* stream) {
+  STIL_REQUIRE(logits && labels && row_loss && rows > 0 && K > 0, "stil_ce_hard: bad arguments");
+  hipLaunchKernelGGL(ce_hard_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, row_loss, dlogits,
+                     ldd, K, inv_rows);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" int stil_ce_soft(const float* logits, int ld, const float* targets, int ldq, const float* row_w,
+                            float* row_loss, float* dlogits, int ldd, int rows, int K, float inv_rows, void* stream) {
+  STIL_REQUIRE(logits && targets && row_loss && rows > 0 && K > 0, "stil_ce_soft: bad arguments");
+  hipLaunchKernelGGL(ce_soft_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ld, targets, ldq, row_w,
+                     row_loss, dlogits, ldd, K, inv_rows);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" int stil_reduce_sum(const float* x, int n, float scale, float* out, int accumulate, void* stream) {
+  STIL_REQUIRE(x && out && n >= 0, "stil_reduce_sum: bad arguments");
+  hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, scale, out, accumulate);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" int stil_scale_dev(const float* x, const float* g_dev, float c, float* out, long n, void* stream) {
+  STIL_REQUIRE(x && g_dev && out, "stil_scale_dev: null pointer");
+  hipLaunchKernelGGL(scale_dev_kernel, dim3(ew_grid2(n)), dim3(256), 0, (hipStream_t)stream, x, g_dev, c, out, n);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" int stil_l2norm_fwd(const float* x, float* y, float* norms, int rows, int D, void* stream) {
+  STIL_REQUIRE(x && y && norms && rows > 0, "stil_l2norm_fwd: bad arguments");
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y, norms, rows, D);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+extern "C" int stil_l2norm_bwd(const float* g, const float* y, const float* norms, float* dx, int rows, int D,
+                               void* stream) {
+  STIL_REQUIRE(g && y && norms && dx && rows > 0, "stil_l2norm_bwd: bad arguments");
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, g, y, norms, dx, rows, D);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+// Z: [B,B] logits (already / T). lse: [2,B] (rows, cols). terms: [B] scratch. loss: scalar.
+extern "C" int stil_clip_fwd(const float* Z, float* lse, float* terms, float* loss, int B, float lam0, float lam1,
+                             void* stream) {
+  STIL_REQUIRE(Z && lse && terms && loss && B > 0, "stil_clip_fwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(lse_rows_kernel, dim3(B), dim3(256), 0, s, Z, lse, B, B);
+  STIL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(lse_cols_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, Z, lse + B, B, B);
+  STIL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(clip_terms_kernel, dim3(cdiv(B, 256)), dim3(256), 0, s, Z, lse, lse + B, terms, B, lam0, lam1);
+  STIL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, s, terms, B, 1.f / (float)B, loss, 0);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+extern "C" int stil_clip_bwd(const float* Z, const float* lse, const float* g_dev, float* dZ, int B, float lam0,
+                             float lam1, void* stream) {
+  STIL_REQUIRE(Z && lse && g_dev && dZ && B > 0, "stil_clip_bwd: bad arguments");
+  hipLaunchKernelGGL(clip_dz_kernel, dim3(ew_grid2((long)B * B)), dim3(256), 0, (hipStream_t)stream, Z, lse, lse + B,
+                     g_dev, dZ, B, lam0, lam1);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+// ybar must hold the column means of y.  rows_tmp: [2,R] scratch.  out: club -> out2[0], est -> out2[1]
+extern "C" int stil_club_fwd(const float* mu, const float* y, const float* ybar, float* rows_tmp, float* out2, int R,
+                             int D, void* stream) {
+  STIL_REQUIRE(mu && y && ybar && rows_tmp && out2 && R > 0, "stil_club_fwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(club_rows_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, mu, y, ybar, rows_tmp, rows_tmp + R, R, D);
+  STIL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, s, rows_tmp, R, 0.5f / (float)R, out2, 0);
+  STIL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, s, rows_tmp + R, R, 1.f / (float)R, out2 + 1, 0);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+extern "C" int stil_club_bwd(const float* mu, const float* y, const float* ybar, const float* mubar,
+                             const float* g_club_dev, const float* g_est_dev, float* dmu, float* dy, int R, int D,
+                             void* stream) {
+  STIL_REQUIRE(mu && y && ybar && mubar && g_club_dev && g_est_dev && dmu && dy, "stil_club_bwd: null pointer");
+  hipLaunchKernelGGL(club_bwd_kernel, dim3(ew_grid2((long)R * D)), dim3(256), 0, (hipStream_t)stream, mu, y, ybar, mubar,
+                     g_club_dev, g_est_dev, dmu, dy, R, D);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" int stil_cgpl_pgls(const float* zm, const float* zi, const float* zt, int ldz, const float* feat_u,
+                              const float* prototypes, const unsigned char* mask_random, float* pseudo_label,
+                              float* pseudo_orig, float* prediction, unsigned char* flags, int* hard, float* w3, int Bu,
+                              int K, int Dp, float rate_pseudo, float T, float th, int use_pseudo, void* stream) {
+  STIL_REQUIRE(zm && zi && zt && feat_u && prototypes && mask_random && pseudo_label && prediction && flags && hard && w3,
+               "stil_cgpl_pgls: null pointer");
+  STIL_REQUIRE(Bu > 0 && K > 0 && (size_t)3 * K * sizeof(float) <= 60 * 1024, "stil_cgpl_pgls: bad shape (Bu=%d K=%d)", Bu, K);
+  CgplArgs p;
+  p.zm = zm; p.zi = zi; p.zt = zt; p.ldz = ldz; p.feat = feat_u; p.Dp = Dp; p.protos = prototypes;
+  p.mask_random = mask_random; p.pseudo_label = pseudo_label; p.pseudo_orig = pseudo_orig; p.prediction = prediction;
+  p.flags = flags; p.hard = hard; p.w3 = w3; p.K = K; p.r = rate_pseudo; p.T = T; p.th = th; p.use_pseudo = use_pseudo;
+  hipLaunchKernelGGL(cgpl_pgls_kernel, dim3(Bu), dim3(256), (size_t)3 * K * sizeof(float), (hipStream_t)stream, p);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" int stil_proto_loss(const float* feat, const float* prototypes, const int* hard, const unsigned char* conf,
+                               float* row_loss, float* dfeat_unit, int rows, int K, int Dp, float T, void* stream) {
+  STIL_REQUIRE(feat && prototypes && hard && conf && row_loss && rows > 0, "stil_proto_loss: bad arguments");
+  STIL_REQUIRE((size_t)K * sizeof(float) <= 60 * 1024, "stil_proto_loss: K=%d too large", K);
+  hipLaunchKernelGGL(proto_loss_kernel, dim3(rows), dim3(256), (size_t)K * sizeof(float), (hipStream_t)stream, feat,
+                     prototypes, hard, conf, row_loss, dfeat_unit, K, Dp, T, 1.f / (float)rows);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" int stil_proto_accum(const float* feat_e, const int* hard, const unsigned char* conf, float* class_sum_cnt,
+                                int B, int B_l, int K, int Dp, float repeat_ratio, void* stream) {
+  STIL_REQUIRE(feat_e && hard && conf && class_sum_cnt && repeat_ratio > 0.f, "stil_proto_accum: bad arguments");
+  hipLaunchKernelGGL(proto_accum_kernel, dim3(K), dim3(192), 0, (hipStream_t)stream, feat_e, hard, conf, class_sum_cnt,
+                     B, B_l, Dp, 1.f / repeat_ratio);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+extern "C" int stil_proto_add(const float* class_sum_cnt, float* prototypes_sum, float* prototypes_count_sum, int K,
+                              int Dp, void* stream) {
+  STIL_REQUIRE(class_sum_cnt && prototypes_sum && prototypes_count_sum, "stil_proto_add: null pointer");
+  hipLaunchKernelGGL(proto_add_kernel, dim3(cdiv((long)K * (Dp + 1), 256)), dim3(256), 0, (hipStream_t)stream,
+                     class_sum_cnt, prototypes_sum, prototypes_count_sum, K, Dp);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+// bad_count_dev[0] must be zeroed by the caller; >0 afterwards == the reference's assert (STiLModel.py:412) fails
+extern "C" int stil_proto_commit(float* prototypes, float* prototypes_sum, float* prototypes_count_sum,
+                                 int* bad_count_dev, int K, int Dp, void* stream) {
+  STIL_REQUIRE(prototypes && prototypes_sum && prototypes_count_sum && bad_count_dev, "stil_proto_commit: null pointer");
+  hipLaunchKernelGGL(proto_commit_kernel, dim3(K), dim3(128), 0, (hipStream_t)stream, prototypes, prototypes_sum,
+                     prototypes_count_sum, bad_count_dev, K, Dp);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}

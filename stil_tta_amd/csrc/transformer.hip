@@ -1,0 +1,612 @@
+// Transformer-side kernels: LayerNorm, fused small-sequence attention (S <= 128 lives in LDS),
+// activation backward, dropout / drop-path, tabular embedding, token means, transposes.
+// Replaces the ATen sequences of models/Transformer.py:63-88,165-174,240-259 and
+// models/Disentangle/utils/disentangle_transformer.py:49-94,151-169.
+#include "common.h"
+
+// ---------------------------------------------------------------- LayerNorm (one wave per row)
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ y,
+                                                             float* __restrict__ mean_rstd, int rows, int D, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (long)row * D;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) s += xr[i];
+  const float mean = wave_sum(s) / (float)D;
+  float v = 0.f;
+  for (int i = lane; i < D; i += 64) { float d = xr[i] - mean; v += d * d; }
+  const float rstd = 1.f / sqrtf(wave_sum(v) / (float)D + eps);
+  float* yr = y + (long)row * D;
+  for (int i = lane; i < D; i += 64) yr[i] = (xr[i] - mean) * rstd * gamma[i] + beta[i];
+  if (lane == 0) { mean_rstd[2 * row] = mean; mean_rstd[2 * row + 1] = rstd; }
+}
+
+// dx per row; per-block column partials of dgamma (g*xhat) and dbeta (g): part[blk][2][D]
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ mean_rstd, float* __restrict__ dx,
+                                                             float* __restrict__ part, int rows, int D,
+                                                             int rows_per_block) {
+  extern __shared__ float sh[];  // [4][2][D]
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float* my = sh + (long)w * 2 * D;
+  for (int i = lane; i < 2 * D; i += 64) my[i] = 0.f;
+  for (int row = r0 + w; row < r1; row += 4) {
+    const float* xr = x + (long)row * D;
+    const float* gr = g + (long)row * D;
+    const float mean = mean_rstd[2 * row], rstd = mean_rstd[2 * row + 1];
+    float a = 0.f, b = 0.f;
+    for (int i = lane; i < D; i += 64) {
+      float gg = gr[i] * gamma[i], xh = (xr[i] - mean) * rstd;
+      a += gg; b += gg * xh;
+      my[i] += gr[i] * xh;      // lane-private columns: no race
+      my[D + i] += gr[i];
+    }
+    a = wave_sum(a) / (float)D; b = wave_sum(b) / (float)D;
+    float* dr = dx + (long)row * D;
+    for (int i = lane; i < D; i += 64) {
+      float xh = (xr[i] - mean) * rstd;
+      dr[i] = rstd * (gr[i] * gamma[i] - a - xh * b);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * D; i += 256)
+    part[(long)blockIdx.x * 2 * D + i] = sh[i] + sh[2 * D + i] + sh[4 * D + i] + sh[6 * D + i];
+}
+
+__global__ void ln_final_kernel(const float* __restrict__ part, int nblk, int D, float* __restrict__ dgamma,
+                                float* __restrict__ dbeta, int accumulate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  float a = 0.f, b = 0.f;
+  for (int i = 0; i < nblk; ++i) { a += part[(long)i * 2 * D + c]; b += part[(long)i * 2 * D + D + c]; }
+  dgamma[c] = accumulate ? dgamma[c] + a : a;
+  dbeta[c] = accumulate ? dbeta[c] + b : b;
+}
+
+// ---------------------------------------------------------------- fused attention, one block per (batch, head)
+struct AttnArgs {
+  const float* qkv;  // [B, T, 3, H, d]
+  float* out;        // fwd: [B, T, H*d]   (rows q_off..q_off+Sq)
+  float* probs;      // [B, H, Sq, Skv] softmax (pre-dropout)
+  const unsigned char* mask;  // optional keep-mask [B, H, Sq, Skv]
+  const float* dout;  // bwd
+  float* dqkv;        // bwd: accumulated (+=) into [B, T, 3, H, d]
+  int B, T, H, d, q_off, Sq, kv_off, Skv;
+  float scale, drop_scale;
+};
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];
+  const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+  const int d = p.d, dp = d + 4, Sq = p.Sq, Skv = p.Skv, d4 = d >> 2;
+  float* Qs = sh;                 // [Sq][d]
+  float* Ks = Qs + Sq * d;        // [Skv][dp]  (K, then V)
+  float* Ps = Ks + Skv * dp;      // [Sq][Skv]
+  const long ld = 3L * p.H * d;
+  const float* base = p.qkv + (long)b * p.T * ld + h * d;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < Sq * d4; i += 256) {
+    int r = i / d4, c = i - r * d4;
+    *reinterpret_cast<float4*>(Qs + r * d + c * 4) = *reinterpret_cast<const float4*>(base + (long)(p.q_off + r) * ld + c * 4);
+  }
+  for (int i = tid; i < Skv * d4; i += 256) {
+    int r = i / d4, c = i - r * d4;
+    *reinterpret_cast<float4*>(Ks + r * dp + c * 4) =
+        *reinterpret_cast<const float4*>(base + (long)(p.kv_off + r) * ld + p.H * d + c * 4);
+  }
+  __syncthreads();
+  for (int e = tid; e < Sq * Skv; e += 256) {
+    int i = e / Skv, j = e - i * Skv;
+    const float4* q = reinterpret_cast<const float4*>(Qs + i * d);
+    const float4* k = reinterpret_cast<const float4*>(Ks + j * dp);
+    float s = 0.f;
+    for (int c = 0; c < d4; ++c) {
+      float4 a = q[c], bb = k[c];
+      s += a.x * bb.x; s += a.y * bb.y; s += a.z * bb.z; s += a.w * bb.w;
+    }
+    Ps[e] = s * p.scale;
+  }
+  __syncthreads();
+  // V overwrites K (all score reads are done)
+  for (int i = tid; i < Skv * d4; i += 256) {
+    int r = i / d4, c = i - r * d4;
+    *reinterpret_cast<float4*>(Ks + r * dp + c * 4) =
+        *reinterpret_cast<const float4*>(base + (long)(p.kv_off + r) * ld + 2 * p.H * d + c * 4);
+  }
+  const int w = tid >> 6, lane = tid & 63;
+  float* pg = p.probs + ((long)(b * p.H + h) * Sq) * Skv;
+  const unsigned char* mk = p.mask ? p.mask + ((long)(b * p.H + h) * Sq) * Skv : nullptr;
+  for (int i = w; i < Sq; i += 4) {
+    float* pr = Ps + i * Skv;
+    float m = -INFINITY;
+    for (int j = lane; j < Skv; j += 64) m = fmaxf(m, pr[j]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int j = lane; j < Skv; j += 64) { float e = expf(pr[j] - m); pr[j] = e; s += e; }
+    s = wave_sum(s);
+    const float inv = 1.f / s;
+    for (int j = lane; j < Skv; j += 64) {
+      float pv = pr[j] * inv;
+      pg[(long)i * Skv + j] = pv;
+      if (mk) pv = mk[(long)i * Skv + j] ? pv * p.drop_scale : 0.f;
+      pr[j] = pv;
+    }
+  }
+  __syncthreads();
+  float* ob = p.out + ((long)b * p.T + p.q_off) * (p.H * d) + h * d;
+  for (int e = tid; e < Sq * d4; e += 256) {
+    int i = e / d4, c = e - i * d4;
+    const float* pr = Ps + i * Skv;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < Skv; ++j) {
+      const float pj = pr[j];
+      const float4 v = *reinterpret_cast<const float4*>(Ks + j * dp + c * 4);
+      acc.x += pj * v.x; acc.y += pj * v.y; acc.z += pj * v.z; acc.w += pj * v.w;
+    }
+    *reinterpret_cast<float4*>(ob + (long)i * (p.H * d) + c * 4) = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];
+  const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+  const int d = p.d, dp = d + 4, Sq = p.Sq, Skv = p.Skv, d4 = d >> 2;
+  const int Smax = Sq > Skv ? Sq : Skv;
+  float* Ab = sh;                  // [Smax][dp]  dO, later Q
+  float* Bb = Ab + Smax * dp;      // [Smax][dp]  V, later K
+  float* dS = Bb + Smax * dp;      // [Sq][Skv]
+  float* Pd = dS + Sq * Skv;       // [Sq][Skv]  dropped probs
+  const long ld = 3L * p.H * d;
+  const float* base = p.qkv + (long)b * p.T * ld + h * d;
+  float* dbase = p.dqkv + (long)b * p.T * ld + h * d;
+  const float* dob = p.dout + ((long)b * p.T + p.q_off) * (p.H * d) + h * d;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < Sq * d4; i += 256) {
+    int r = i / d4, c = i - r * d4;
+    *reinterpret_cast<float4*>(Ab + r * dp + c * 4) = *reinterpret_cast<const float4*>(dob + (long)r * (p.H * d) + c * 4);
+  }
+  for (int i = tid; i < Skv * d4; i += 256) {
+    int r = i / d4, c = i - r * d4;
+    *reinterpret_cast<float4*>(Bb + r * dp + c * 4) =
+        *reinterpret_cast<const float4*>(base + (long)(p.kv_off + r) * ld + 2 * p.H * d + c * 4);
+  }
+  __syncthreads();
+  const float* pg = p.probs + ((long)(b * p.H + h) * Sq) * Skv;
+  const unsigned char* mk = p.mask ? p.mask + ((long)(b * p.H + h) * Sq) * Skv : nullptr;
+  // dPd = dO V^T ; dP = dPd * mask * drop_scale
+  for (int e = tid; e < Sq * Skv; e += 256) {
+    int i = e / Skv, j = e - i * Skv;
+    const float4* a = reinterpret_cast<const float4*>(Ab + i * dp);
+    const float4* v = reinterpret_cast<const float4*>(Bb + j * dp);
+    float s = 0.f;
+    for (int c = 0; c < d4; ++c) {
+      float4 x = a[c], y = v[c];
+      s += x.x * y.x; s += x.y * y.y; s += x.z * y.z; s += x.w * y.w;
+    }
+    float keep = 1.f;
+    if (mk) keep = mk[e] ? p.drop_scale : 0.f;
+    const float pv = pg[e];
+    dS[e] = s * keep;      // dP
+    Pd[e] = pv * keep;     // dropped probs (for dV)
+  }
+  __syncthreads();
+  // dS = P * (dP - rowsum(dP*P)) * scale
+  for (int i = w; i < Sq; i += 4) {
+    float s = 0.f;
+    for (int j = lane; j < Skv; j += 64) s += dS[i * Skv + j] * pg[(long)i * Skv + j];
+    s = wave_sum(s);
+    for (int j = lane; j < Skv; j += 64) dS[i * Skv + j] = pg[(long)i * Skv + j] * (dS[i * Skv + j] - s) * p.scale;
+  }
+  __syncthreads();
+  // dV[j][c] += sum_i Pd[i][j] dO[i][c]
+  for (int e = tid; e < Skv * d4; e += 256) {
+    int j = e / d4, c = e - j * d4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < Sq; ++i) {
+      const float pj = Pd[i * Skv + j];
+      const float4 v = *reinterpret_cast<const float4*>(Ab + i * dp + c * 4);
+      acc.x += pj * v.x; acc.y += pj * v.y; acc.z += pj * v.z; acc.w += pj * v.w;
+    }
+    float4* dst = reinterpret_cast<float4*>(dbase + (long)(p.kv_off + j) * ld + 2 * p.H * d + c * 4);
+    float4 o = *dst;
+    o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+    *dst = o;
+  }
+  __syncthreads();
+  // K -> Bb ; Q -> Ab
+  for (int i = tid; i < Skv * d4; i += 256) {
+    int r = i / d4, c = i - r * d4;
+    *reinterpret_cast<float4*>(Bb + r * dp + c * 4) =
+        *reinterpret_cast<const float4*>(base + (long)(p.kv_off + r) * ld + p.H * d + c * 4);
+  }
+  for (int i = tid; i < Sq * d4; i += 256) {
+    int r = i / d4, c = i - r * d4;
+    *reinterpret_cast<float4*>(Ab + r * dp + c * 4) = *reinterpret_cast<const float4*>(base + (long)(p.q_off + r) * ld + c * 4);
+  }
+  __syncthreads();
+  // dQ[i][c] += sum_j dS[i][j] K[j][c]
+  for (int e = tid; e < Sq * d4; e += 256) {
+    int i = e / d4, c = e - i * d4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < Skv; ++j) {
+      const float s = dS[i * Skv + j];
+      const float4 v = *reinterpret_cast<const float4*>(Bb + j * dp + c * 4);
+      acc.x += s * v.x; acc.y += s * v.y; acc.z += s * v.z; acc.w += s * v.w;
+    }
+    float4* dst = reinterpret_cast<float4*>(dbase + (long)(p.q_off + i) * ld + c * 4);
+    float4 o = *dst;
+    o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+    *dst = o;
+  }
+  // dK[j][c] += sum_i dS[i][j] Q[i][c]   (different destination rows/slot than dQ: no hazard within the block)
+  for (int e = tid; e < Skv * d4; e += 256) {
+    int j = e / d4, c = e - j * d4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < Sq; ++i) {
+      const float s = dS[i * Skv + j];
+      const float4 v = *reinterpret_cast<const float4*>(Ab + i * dp + c * 4);
+      acc.x += s * v.x; acc.y += s * v.y; acc.z += s * v.z; acc.w += s * v.w;
+    }
+    float4* dst = reinterpret_cast<float4*>(dbase + (long)(p.kv_off + j) * ld + p.H * d + c * 4);
+    float4 o = *dst;
+    o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+    *dst = o;
+  }
+}
+
+// ---------------------------------------------------------------- elementwise
+// kind 1: dx = dy * (ref > 0)   (ref = relu output) ; kind 2: dx = dy * gelu'(ref)  (ref = pre-activation)
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ ref, float* __restrict__ dx,
+                               long n, int kind) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float r = ref[i];
+    dx[i] = kind == 1 ? (r > 0.f ? dy[i] : 0.f) : dy[i] * gelu_grad_f(r);
+  }
+}
+
+// out = (resid ? resid : 0) + x * emask[i] * rmask[i / rowlen] * scale
+__global__ void drop_add_kernel(const float* __restrict__ x, const float* __restrict__ resid,
+                                const unsigned char* __restrict__ emask, const unsigned char* __restrict__ rmask,
+                                float* __restrict__ out, long n, int rowlen, float scale) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float k = scale;
+    if (emask && !emask[i]) k = 0.f;
+    if (rmask && !rmask[i / rowlen]) k = 0.f;
+    float v = x[i] * k;
+    if (resid) v += resid[i];
+    out[i] = v;
+  }
+}
+
+// out = a*x + b*y (y optional)
+__global__ void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, long n,
+                             float a, float b) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = a * x[i] + (y ? b * y[i] : 0.f);
+}
+
+// keep-mask generation: counter-based hash (seed, offset + i) -> uniform [0,1) >= p
+__device__ __forceinline__ unsigned int hash_u32(unsigned long long x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return (unsigned int)(x >> 16);
+}
+__global__ void rng_mask_kernel(unsigned char* __restrict__ out, long n, unsigned long long seed,
+                                unsigned long long offset, float p) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    unsigned int r = hash_u32(seed * 0x9E3779B97F4A7C15ULL + offset + (unsigned long long)i);
+    float u = (float)(r >> 8) * (1.0f / 16777216.0f);
+    out[i] = u >= p ? 1 : 0;
+  }
+}
+
+// out[c][r] = in[r][c]
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
+  __shared__ float t[32][33];
+  int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
+  for (int k = ty; k < 32; k += 8) {
+    int r = r0 + k, c = c0 + tx;
+    t[k][tx] = (r < R && c < C) ? in[(long)r * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    int c = c0 + k, r = r0 + tx;
+    if (r < R && c < C) out[(long)c * R + r] = t[tx][k];
+  }
+}
+
+// conv weight re-layout: w (Cout,Cin,KH,KW) -> wf [Cout][KH*KW][Cin] (forward) and wd [Cin][KH*KW][Cout] (dgrad)
+__global__ void conv_w_layout_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wd,
+                                     int Cout, int Cin, int taps) {
+  long total = (long)Cout * Cin * taps;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int tap = (int)(i % taps);
+    long t = i / taps;
+    int ci = (int)(t % Cin), co = (int)(t / Cin);
+    float v = w[i];
+    if (wf) wf[((long)co * taps + tap) * Cin + ci] = v;
+    if (wd) wd[((long)ci * taps + tap) * Cout + co] = v;
+  }
+}
+
+// ---------------------------------------------------------------- tabular embedding
+// h[b,0]=cls ; h[b,1+j]=cat_emb[int(x[b,j])+off[j]] (j<ncat) ; h[b,1+j]=x[b,j]*w+bias (j>=ncat) ; + colemb[t]
+__global__ void tab_embed_fwd_kernel(const float* __restrict__ x, const int* __restrict__ offs,
+                                     const float* __restrict__ emb, const float* __restrict__ con_w,
+                                     const float* __restrict__ con_b, const float* __restrict__ cls,
+                                     const float* __restrict__ colemb, float* __restrict__ h, int B, int ncols, int ncat,
+                                     int D) {
+  const int T = ncols + 1;
+  long total = (long)B * T * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int dd = (int)(i % D);
+    long r = i / D;
+    int t = (int)(r % T), b = (int)(r / T);
+    float v;
+    if (t == 0) v = cls[dd];
+    else if (t - 1 < ncat) {
+      long code = (long)x[(long)b * ncols + t - 1] + offs[t - 1];
+      v = emb[code * D + dd];
+    } else v = x[(long)b * ncols + t - 1] * con_w[dd] + con_b[dd];
+    h[i] = v + colemb[(long)t * D + dd];
+  }
+}
+
+// per token position t: dcol[t,d] = sum_b g[b,t,d] ; tmpw[t,d] = sum_b g[b,t,d]*x[b,t-1] (continuous tokens)
+__global__ void tab_embed_bwd_tok_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                         float* __restrict__ dcol, float* __restrict__ tmpw, int B, int ncols, int ncat,
+                                         int D, int accumulate) {
+  const int T = ncols + 1, t = blockIdx.x;
+  const bool con = (t >= 1 + ncat);
+  for (int dd = threadIdx.x; dd < D; dd += blockDim.x) {
+    float s = 0.f, sw = 0.f;
+    for (int b = 0; b < B; ++b) {
+      float gv = g[((long)b * T + t) * D + dd];
+      s += gv;
+      if (con) sw += gv * x[(long)b * ncols + t - 1];
+    }
+    long o = (long)t * D + dd;
+    tmpw[o] = sw;
+    tmpw[(long)T * D + o] = s;
+    dcol[o] = accumulate ? dcol[o] + s : s;
+  }
+}
+// dcls, dcon_w, dcon_b from the per-token sums
+__global__ void tab_embed_bwd_fin_kernel(const float* __restrict__ tmpw, float* __restrict__ dcls,
+                                         float* __restrict__ dcon_w, float* __restrict__ dcon_b, int ncols, int ncat,
+                                         int D, int accumulate) {
+  const int T = ncols + 1;
+  int dd = blockIdx.x * blockDim.x + threadIdx.x;
+  if (dd >= D) return;
+  float sw = 0.f, sb = 0.f;
+  for (int t = 1 + ncat; t < T; ++t) { sw += tmpw[(long)t * D + dd]; sb += tmpw[(long)T * D + (long)t * D + dd]; }
+  float c = tmpw[(long)T * D + dd];
+  dcls[dd] = accumulate ? dcls[dd] + c : c;
+  if (ncols > ncat) {
+    dcon_w[dd] = accumulate ? dcon_w[dd] + sw : sw;
+    dcon_b[dd] = accumulate ? dcon_b[dd] + sb : sb;
+  }
+}
+// embedding rows: block per table row r (column rowcol[r]); deterministic loop over the batch
+__global__ void tab_embed_bwd_emb_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                         const int* __restrict__ offs, const int* __restrict__ rowcol,
+                                         float* __restrict__ demb, int B, int ncols, int D, int accumulate) {
+  const int T = ncols + 1, r = blockIdx.x, j = rowcol[r];
+  const int code = r - offs[j];
+  for (int dd = threadIdx.x; dd < D; dd += blockDim.x) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b)
+      if ((int)x[(long)b * ncols + j] == code) s += g[((long)b * T + j + 1) * D + dd];
+    long o = (long)r * D + dd;
+    demb[o] = accumulate ? demb[o] + s : s;
+  }
+}
+
+// ---------------------------------------------------------------- token mean over dim 1 of [B,T,D]
+__global__ void tokmean_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int T, int D) {
+  long total = (long)B * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int dd = (int)(i % D), b = (int)(i / D);
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += x[((long)b * T + t) * D + dd];
+    y[i] = s / (float)T;
+  }
+}
+__global__ void tokmean_bwd_kernel(const float* __restrict__ g, float* __restrict__ dx, int B, int T, int D) {
+  long total = (long)B * T * D;
+  const float inv = 1.f / (float)T;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int dd = (int)(i % D);
+    int b = (int)(i / ((long)T * D));
+    dx[i] = g[(long)b * D + dd] * inv;
+  }
+}
+
+// ---------------------------------------------------------------- C ABI
+static inline int ew_grid(long n) { long g = (n + 255) / 256; return (int)(g < 16384 ? (g < 1 ? 1 : g) : 16384); }
+
+extern "C" int stil_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean_rstd,
+                                  int rows, int D, float eps, void* stream) {
+  STIL_REQUIRE(x && gamma && beta && y && mean_rstd && rows > 0 && D > 0, "stil_layernorm_fwd: bad arguments");
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
+                     mean_rstd, rows, D, eps);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+static inline int ln_blocks(int rows) { int nb = cdiv(rows, 32); return nb > 1024 ? 1024 : nb; }
+extern "C" size_t stil_layernorm_bwd_workspace_bytes(int rows, int D) { return (size_t)ln_blocks(rows) * 2 * D * sizeof(float); }
+
+extern "C" int stil_layernorm_bwd(const float* g, const float* x, const float* gamma, const float* mean_rstd,
+                                  float* dx, float* dgamma, float* dbeta, int rows, int D, int accumulate,
+                                  float* workspace, size_t workspace_bytes, void* stream) {
+  STIL_REQUIRE(g && x && gamma && mean_rstd && dx && dgamma && dbeta && workspace, "stil_layernorm_bwd: null pointer");
+  STIL_REQUIRE(D <= 4096, "stil_layernorm_bwd: D=%d > 4096", D);
+  int nb = ln_blocks(rows);
+  STIL_REQUIRE(workspace_bytes >= (size_t)nb * 2 * D * sizeof(float), "stil_layernorm_bwd: workspace too small");
+  int rpb = cdiv(rows, nb);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), (size_t)8 * D * sizeof(float), s, g, x, gamma, mean_rstd,
+                     dx, workspace, rows, D, rpb);
+  STIL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ln_final_kernel, dim3(cdiv(D, 64)), dim3(64), 0, s, workspace, nb, D, dgamma, dbeta, accumulate);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+static int attn_check(int T, int H, int d, int q_off, int Sq, int kv_off, int Skv) {
+  STIL_REQUIRE(d % 4 == 0 && d > 0, "attention: head dim %d must be a multiple of 4", d);
+  STIL_REQUIRE(Sq > 0 && Skv > 0 && q_off >= 0 && kv_off >= 0 && q_off + Sq <= T && kv_off + Skv <= T,
+               "attention: window out of range (T=%d q=[%d,+%d) kv=[%d,+%d))", T, q_off, Sq, kv_off, Skv);
+  (void)H;
+  return STIL_OK;
+}
+static bool g_attn_attr_set = false;
+static int attn_set_attr() {
+  if (g_attn_attr_set) return STIL_OK;
+  hipError_t e1 = hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipError_t e2 = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e1 != hipSuccess || e2 != hipSuccess) {
+    stil_set_error("attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    return STIL_EHIP;
+  }
+  g_attn_attr_set = true;
+  return STIL_OK;
+}
+
+extern "C" int stil_attention_fwd(const float* qkv, float* out, float* probs, const unsigned char* mask, int B, int T,
+                                  int H, int d, int q_off, int Sq, int kv_off, int Skv, float scale, float drop_p,
+                                  void* stream) {
+  STIL_REQUIRE(qkv && out && probs, "stil_attention_fwd: null pointer");
+  int rc = attn_check(T, H, d, q_off, Sq, kv_off, Skv);
+  if (rc) return rc;
+  size_t lds = ((size_t)Sq * d + (size_t)Skv * (d + 4) + (size_t)Sq * Skv) * sizeof(float);
+  STIL_REQUIRE(lds <= 160 * 1024, "stil_attention_fwd: needs %zu B of LDS (> 160 KiB): Sq=%d Skv=%d d=%d", lds, Sq, Skv, d);
+  if ((rc = attn_set_attr())) return rc;
+  AttnArgs p;
+  p.qkv = qkv; p.out = out; p.probs = probs; p.mask = mask; p.dout = nullptr; p.dqkv = nullptr;
+  p.B = B; p.T = T; p.H = H; p.d = d; p.q_off = q_off; p.Sq = Sq; p.kv_off = kv_off; p.Skv = Skv;
+  p.scale = scale; p.drop_scale = mask ? 1.f / (1.f - drop_p) : 1.f;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, p);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" int stil_attention_bwd(const float* dout, const float* qkv, const float* probs, const unsigned char* mask,
+                                  float* dqkv, int B, int T, int H, int d, int q_off, int Sq, int kv_off, int Skv,
+                                  float scale, float drop_p, void* stream) {
+  STIL_REQUIRE(dout && qkv && probs && dqkv, "stil_attention_bwd: null pointer");
+  int rc = attn_check(T, H, d, q_off, Sq, kv_off, Skv);
+  if (rc) return rc;
+  int Smax = Sq > Skv ? Sq : Skv;
+  size_t lds = ((size_t)2 * Smax * (d + 4) + (size_t)2 * Sq * Skv) * sizeof(float);
+  STIL_REQUIRE(lds <= 160 * 1024, "stil_attention_bwd: needs %zu B of LDS (> 160 KiB)", lds);
+  if ((rc = attn_set_attr())) return rc;
+  AttnArgs p;
+  p.qkv = qkv; p.out = nullptr; p.probs = const_cast<float*>(probs); p.mask = mask; p.dout = dout; p.dqkv = dqkv;
+  p.B = B; p.T = T; p.H = H; p.d = d; p.q_off = q_off; p.Sq = Sq; p.kv_off = kv_off; p.Skv = Skv;
+  p.scale = scale; p.drop_scale = mask ? 1.f / (1.f - drop_p) : 1.f;
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, p);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" int stil_act_bwd(const float* dy, const float* ref, float* dx, long n, int kind, void* stream) {
+  STIL_REQUIRE(dy && ref && dx && (kind == 1 || kind == 2), "stil_act_bwd: bad arguments");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, ref, dx, n, kind);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" int stil_drop_add(const float* x, const float* resid, const unsigned char* emask, const unsigned char* rmask,
+                             float* out, long n, int rowlen, float scale, void* stream) {
+  STIL_REQUIRE(x && out && rowlen > 0, "stil_drop_add: bad arguments");
+  hipLaunchKernelGGL(drop_add_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, resid, emask, rmask, out,
+                     n, rowlen, scale);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" int stil_axpby(const float* x, const float* y, float* out, long n, float a, float b, void* stream) {
+  STIL_REQUIRE(x && out, "stil_axpby: null pointer");
+  hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, out, n, a, b);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" int stil_rng_mask(unsigned char* out, long n, unsigned long long seed, unsigned long long offset, float p,
+                             void* stream) {
+  STIL_REQUIRE(out && p >= 0.f && p < 1.f, "stil_rng_mask: bad arguments");
+  hipLaunchKernelGGL(rng_mask_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset, p);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" int stil_transpose(const float* in, float* out, int R, int C, void* stream) {
+  STIL_REQUIRE(in && out && R > 0 && C > 0, "stil_transpose: bad arguments");
+  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, (hipStream_t)stream, in, out, R, C);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" int stil_conv_weight_layout(const float* w, float* w_fwd, float* w_dgrad, int Cout, int Cin, int KH, int KW,
+                                       void* stream) {
+  STIL_REQUIRE(w && (w_fwd || w_dgrad), "stil_conv_weight_layout: null pointer");
+  long total = (long)Cout * Cin * KH * KW;
+  hipLaunchKernelGGL(conv_w_layout_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w, w_fwd, w_dgrad,
+                     Cout, Cin, KH * KW);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" int stil_tab_embed_fwd(const float* x, const int* cat_offsets, const float* cat_emb, const float* con_w,
+                                  const float* con_b, const float* cls, const float* colemb, float* h, int B,
+                                  int ncols, int ncat, int D, void* stream) {
+  STIL_REQUIRE(x && cls && colemb && h && (ncat == 0 || (cat_offsets && cat_emb)) && (ncols == ncat || (con_w && con_b)),
+               "stil_tab_embed_fwd: null pointer");
+  long total = (long)B * (ncols + 1) * D;
+  hipLaunchKernelGGL(tab_embed_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, cat_offsets,
+                     cat_emb, con_w, con_b, cls, colemb, h, B, ncols, ncat, D);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" size_t stil_tab_embed_bwd_workspace_bytes(int ncols, int D) { return (size_t)2 * (ncols + 1) * D * sizeof(float); }
+
+extern "C" int stil_tab_embed_bwd(const float* g, const float* x, const int* cat_offsets, const int* rowcol,
+                                  int n_emb_rows, float* d_emb, float* d_con_w, float* d_con_b, float* d_cls,
+                                  float* d_colemb, int B, int ncols, int ncat, int D, int accumulate, float* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  STIL_REQUIRE(g && x && d_cls && d_colemb && workspace, "stil_tab_embed_bwd: null pointer");
+  STIL_REQUIRE(workspace_bytes >= stil_tab_embed_bwd_workspace_bytes(ncols, D), "stil_tab_embed_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(tab_embed_bwd_tok_kernel, dim3(ncols + 1), dim3(256), 0, s, g, x, d_colemb, workspace, B, ncols,
+                     ncat, D, accumulate);
+  STIL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(tab_embed_bwd_fin_kernel, dim3(cdiv(D, 64)), dim3(64), 0, s, workspace, d_cls, d_con_w, d_con_b,
+                     ncols, ncat, D, accumulate);
+  STIL_LAUNCH_CHECK();
+  if (ncat > 0 && n_emb_rows > 0) {
+    STIL_REQUIRE(cat_offsets && rowcol && d_emb, "stil_tab_embed_bwd: null categorical pointers");
+    hipLaunchKernelGGL(tab_embed_bwd_emb_kernel, dim3(n_emb_rows), dim3(256), 0, s, g, x, cat_offsets, rowcol, d_emb, B,
+                       ncols, D, accumulate);
+    STIL_LAUNCH_CHECK();
+  }
+  return STIL_OK;
+}
+
+extern "C" int stil_tokmean_fwd(const float* x, float* y, int B, int T, int D, void* stream) {
+  STIL_REQUIRE(x && y && T > 0, "stil_tokmean_fwd: bad arguments");
+  hipLaunchKernelGGL(tokmean_fwd_kernel, dim3(ew_grid((long)B * D)), dim3(256), 0, (hipStream_t)stream, x, y, B, T, D);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+extern "C" int stil_tokmean_bwd(const float* g, float* dx, int B, int T, int D, void* stream) {
+  STIL_REQUIRE(g && dx && T > 0, "stil_tokmean_bwd: bad arguments");
+  hipLaunchKernelGGL(tokmean_bwd_kernel, dim3(ew_grid((long)B * T * D)), dim3(256), 0, (hipStream_t)stream, g, dx, B, T, D);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}

@@ -1,0 +1,108 @@
+"""Minimal step driver: what Lightning's automatic optimisation does around STiLModel.training_step
+(trainers/evaluate.py:178-179: zero_grad -> training_step -> backward -> optimizer.step), plus the
+data-parallel gradient exchange (one RCCL all-reduce of the flat gradient slab over xGMI) and the
+reference's LR schedule.  One process per GPU; torch.distributed (backend "nccl" == RCCL on ROCm).
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+def anneal_lambda(warmup_epochs: int, max_epochs: int):
+    """pl_bolts LinearWarmupCosineAnnealingLR(warmup_start_lr=0, eta_min=0) as a LambdaLR factor (STiLModel.py:583)."""
+
+    def f(epoch: int) -> float:
+        if epoch < warmup_epochs:
+            return epoch / max(1, warmup_epochs - 1)
+        return 0.5 * (1.0 + math.cos(math.pi * (epoch - warmup_epochs) / max(1, max_epochs - warmup_epochs)))
+
+    return f
+
+
+def init_distributed(backend: Optional[str] = None):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run). Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def allreduce_flat(slab: torch.Tensor, bucket_elems: int = 64 << 20):
+    """SUM all-reduce of a flat fp32 slab in a few large buckets (xGMI is per-link bound: big messages).
+    Returns the factor the consumer must scale by (1/world) -- applied inside the Adam kernel."""
+    w = world_size()
+    if w == 1:
+        return 1.0
+    n = slab.numel()
+    works = []
+    for o in range(0, n, bucket_elems):
+        works.append(dist.all_reduce(slab[o:min(n, o + bucket_elems)], op=dist.ReduceOp.SUM, async_op=True))
+    for wk in works:
+        wk.wait()
+    return 1.0 / w
+
+
+def train_step(model, optimizer, batch, mask_random=None, mi_masks=None):
+    """One optimisation step. Returns the (detached) loss tensor; no host sync."""
+    optimizer.zero_grad()
+    loss = model.training_step(batch, 0, mask_random=mask_random, mi_masks=mi_masks)
+    loss.backward()
+    optimizer.grad_scale = allreduce_flat(model.flat.grads)
+    optimizer.step()
+    return loss.detach()
+
+
+def shard_batch(batch, rank: int, world: int):
+    """Data-parallel shard keeping the labelled:unlabelled ratio on every rank."""
+    if world == 1:
+        return batch
+
+    def cut(t, n):
+        per = n // world
+        return t[rank * per:(rank + 1) * per]
+
+    out = {}
+    for key in ("l", "u"):
+        im, tab, y, orig, ident = batch[key]
+        n = len(y)
+        out[key] = ([cut(im[0], n), cut(im[1], n)], [cut(tab[0], n), cut(tab[1], n)], cut(y, n), cut(orig, n), cut(ident, n))
+    return out
+
+
+def synthetic_batch(field_lengths, num_classes: int, B: int, img_size: int, seed: int = 2022, device="cpu"):
+    """Synthetic batch of BASELINE.md section 3 in the reference's layout; generated on the host
+    with torch.Generator(seed) so every rank / the CPU baseline see identical data."""
+    g = torch.Generator().manual_seed(seed)
+    cat = [int(c) for c in field_lengths if int(c) != 1]
+    ncon = sum(1 for c in field_lengths if int(c) == 1)
+    B_l = max(B // 8, 1)
+    img = torch.rand(B, 3, img_size, img_size, generator=g)
+    cols = [torch.randint(0, c, (B, 1), generator=g).float() for c in cat]
+    cols.append(torch.randn(B, ncon, generator=g))
+    tab = torch.cat(cols, dim=1)
+    y = torch.randint(0, num_classes, (B,), generator=g)
+    img, tab, y = img.to(device), tab.to(device), y.to(device)
+
+    def part(sl, lab):
+        n = sl.stop - sl.start
+        return ([torch.zeros(n, device=device), img[sl]], [tab[sl], tab[sl]], y[sl], img[sl],
+                torch.full((n,), lab, dtype=torch.bool, device=device))
+
+    return {"l": part(slice(0, B_l), True), "u": part(slice(B_l, B), False)}

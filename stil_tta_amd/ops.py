@@ -1,0 +1,699 @@
+"""Host-side operator layer: torch.autograd.Functions over the C ABI of libstil_hip.so.
+
+PyTorch is used for device memory (allocator), streams and autograd bookkeeping only; every
+arithmetic kernel below is hand-written HIP reached through include/stil_hip.h.  Parameter
+gradients are accumulated straight into the flat gradient slab (see flat.py) when the parameter
+carries a `_gslot` view, so no ATen accumulate kernels run for the 406 parameter tensors.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from ._lib import lib
+
+_vp = ctypes.c_void_p
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else _vp(t.data_ptr())
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("stil_tta_amd ops need CUDA(HIP) tensors: there is no CPU fallback")
+        if not t.is_contiguous():
+            raise RuntimeError("stil_tta_amd ops need contiguous tensors")
+
+
+class _Workspace:
+    """One grow-only scratch buffer per device (all kernels run on one stream, so reuse is ordered)."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        nbytes = max(int(nbytes), 256)
+        b = self.buf.get(device)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+            self.buf[device] = b
+        return b
+
+
+_ws = _Workspace()
+
+
+def _grad_into(param: torch.Tensor, writer):
+    """Run writer(dst, accumulate) for a parameter gradient.  Slab-backed parameters get "+=" into their slot
+    (returns None for autograd); plain tensors get a fresh gradient tensor (returned)."""
+    slot = getattr(param, "_gslot", None)
+    if slot is not None:
+        writer(slot, 1)
+        param._stil_touched = True
+        return None
+    g = torch.empty_like(param)
+    writer(g, 0)
+    return g
+
+
+# ------------------------------------------------------------------------------------------ raw wrappers
+def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None, bias=None, scale=None, shift=None,
+            resid=None, pre=None, act=0, alpha=1.0):
+    """C = epilogue(alpha * Agather . W^T).  geom = (srcH, srcW, srcC, OH, OW, KH, KW, stride, pad, mode)."""
+    if geom is None:
+        geom = (1, 1, K, 1, 1, 1, 1, 1, 0, 0)
+    lda = geom[2] if lda is None else lda
+    ldb = K if ldb is None else ldb
+    ldc = N if ldc is None else ldc
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    L = lib()
+    meta = None
+    if L._prof is not None:  # bench bookkeeping: tile variant + ALGORITHMIC flops (strided dgrad gathers count the conv's flops)
+        s2 = geom[7] * geom[7] if geom[9] == 1 else 1
+        meta = (L.gemm_nt_variant(M, N), 2.0 * M * N * K / s2)
+    L.gemm_nt(_p(A), _p(W), _p(out), M, N, K, lda, ldb, ldc, *geom, _p(bias), _p(scale), _p(shift), _p(resid),
+              (ldc if resid is not None else 0), _p(pre), act, float(alpha), _stream(), meta=meta)
+    return out
+
+
+def wgrad_tn(dY, X, dW, M, N, K, *, ldy=None, ldx=None, geom=None, Kdst=None, accumulate=0):
+    if geom is None:
+        geom = (1, 1, K, 1, 1, 1, 1, 1, 0)
+    ldy = N if ldy is None else ldy
+    ldx = geom[2] if ldx is None else ldx
+    Kdst = K if Kdst is None else Kdst
+    nb = lib().wgrad_workspace_bytes(M, N, K)
+    w = _ws.get(nb, dY.device)
+    lib().wgrad_tn(_p(dY), _p(X), _p(dW), M, N, K, ldy, ldx, *geom, Kdst, accumulate, _p(w), nb, _stream())
+
+
+def colsum(X, out, M, N, *, ld=None, accumulate=0, scale=1.0):
+    nb = lib().colsum_workspace_bytes(M, N)
+    w = _ws.get(nb, X.device)
+    lib().colsum(_p(X), _p(out), M, N, N if ld is None else ld, accumulate, float(scale), _p(w), nb, _stream())
+
+
+def transpose(x2d):
+    R, C = x2d.shape
+    out = torch.empty((C, R), dtype=torch.float32, device=x2d.device)
+    lib().transpose(_p(x2d), _p(out), R, C, _stream())
+    return out
+
+
+def axpby(x, y, a, b, out=None):
+    out = torch.empty_like(x) if out is None else out
+    lib().axpby(_p(x), _p(y), _p(out), x.numel(), float(a), float(b), _stream())
+    return out
+
+
+def rng_mask(shape, p, seed, offset, device):
+    out = torch.empty(shape, dtype=torch.uint8, device=device)
+    lib().rng_mask(_p(out), out.numel(), int(seed), int(offset), float(p), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------ Linear
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b)   nn.Linear (+ReLU / +GELU) -- e.g. models/Transformer.py:27-33."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        _chk(x, weight, bias)
+        K = x.shape[-1]
+        N = weight.shape[0]
+        x2 = x.reshape(-1, K)
+        M = x2.shape[0]
+        pre = torch.empty((M, N), dtype=torch.float32, device=x.device) if act == 2 else None
+        y = gemm_nt(x2, weight, M, N, K, bias=bias, pre=pre, act=act)
+        ctx.act = act
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x2, weight, bias, pre if act == 2 else (y if act == 1 else None))
+        ctx.xshape = x.shape
+        return y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, weight, bias, ref = ctx.saved_tensors
+        M, K = x2.shape
+        N = weight.shape[0]
+        g = gy.contiguous().reshape(M, N)
+        if ctx.act:
+            gp = torch.empty_like(g)
+            lib().act_bwd(_p(g), _p(ref), _p(gp), g.numel(), ctx.act, _stream())
+            g = gp
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = transpose(weight)  # [K, N]
+            dx = gemm_nt(g, wt, M, K, N).reshape(ctx.xshape)
+        dw = _grad_into(weight, lambda dst, acc: wgrad_tn(g, x2, dst, M, N, K, accumulate=acc)) if ctx.needs_input_grad[1] else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _grad_into(bias, lambda dst, acc: colsum(g, dst, M, N, accumulate=acc))
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias=None, act=0):
+    return LinearFn.apply(x, weight, bias, act)
+
+
+class MatmulNTFn(torch.autograd.Function):
+    """Z = alpha * A B^T with gradients to both operands (CLIP logits, utils/clip_loss.py:34)."""
+
+    @staticmethod
+    def forward(ctx, A, B, alpha):
+        _chk(A, B)
+        M, K = A.shape
+        N = B.shape[0]
+        ctx.save_for_backward(A, B)
+        ctx.alpha = alpha
+        return gemm_nt(A, B, M, N, K, alpha=alpha)
+
+    @staticmethod
+    def backward(ctx, gZ):
+        A, B = ctx.saved_tensors
+        M, K = A.shape
+        N = B.shape[0]
+        gZ = gZ.contiguous()
+        dA = gemm_nt(gZ, transpose(B), M, K, N, alpha=ctx.alpha)          # gZ [M,N] . B [N,K]
+        dB = gemm_nt(transpose(gZ), transpose(A), N, K, M, alpha=ctx.alpha)  # gZ^T [N,M] . A [M,K]
+        return dA, dB, None
+
+
+# ------------------------------------------------------------------------------------------ conv + BN (+res) (+relu)
+def _conv_geom_fwd(H, W, C, OH, OW, k, stride, pad):
+    return (H, W, C, OH, OW, k, k, stride, pad, 0)
+
+
+class ConvBnActFn(torch.autograd.Function):
+    """z = relu?( BN_train(conv(x, w)) + residual? ) on NHWC activations.
+
+    One node per conv+BN pair of models/resnets.py:112-132 (Bottleneck) / 71-88 (BasicBlock).
+    x: [N,H,W,Cin] (or the stem's im2col matrix when `stem` is given).
+    """
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, rmean, rvar, nbt, resid, k, stride, pad, relu, stem):
+        _chk(x, w, gamma, beta, resid)
+        Cout = w.shape[0]
+        dev = x.device
+        if stem is not None:  # x is col [M, Kp]; stem = (N, OH, OW, Kp, wpad)
+            Nb, OH, OW, Kp, wpad = stem
+            M = Nb * OH * OW
+            y = gemm_nt(x, wpad, M, Cout, Kp)
+            wf = None
+            geom = None
+        else:
+            Nb, H, W_, Cin = x.shape
+            OH = (H + 2 * pad - k) // stride + 1
+            OW = (W_ + 2 * pad - k) // stride + 1
+            M = Nb * OH * OW
+            if k == 1:
+                wf = w.reshape(Cout, Cin)
+            else:
+                wf = torch.empty((Cout, k * k * Cin), dtype=torch.float32, device=dev)
+                lib().conv_weight_layout(_p(w), _p(wf), None, Cout, Cin, k, k, _stream())
+            geom = _conv_geom_fwd(H, W_, Cin, OH, OW, k, stride, pad)
+            y = gemm_nt(x, wf, M, Cout, k * k * Cin, geom=geom)
+        stats = torch.empty((4, Cout), dtype=torch.float32, device=dev)
+        z = torch.empty((M, Cout), dtype=torch.float32, device=dev)
+        nb = lib().bn_workspace_bytes(M, Cout)
+        ws = _ws.get(nb, dev)
+        lib().bn_train_fwd(_p(y), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(nbt), _p(resid), _p(z), _p(stats), M, Cout,
+                           1 if relu else 0, 1e-5, 0.1, _p(ws), nb, _stream())
+        ctx.save_for_backward(x, w, gamma, beta, y, z, stats)
+        ctx.cfg = (k, stride, pad, relu, stem is not None, resid is not None, geom, (Nb, OH, OW), stem)
+        return z.view(Nb, OH, OW, Cout)
+
+    @staticmethod
+    def backward(ctx, gz):
+        x, w, gamma, beta, y, z, stats = ctx.saved_tensors
+        k, stride, pad, relu, is_stem, has_res, geom, (Nb, OH, OW), stem = ctx.cfg
+        dev = x.device
+        Cout = w.shape[0]
+        M = Nb * OH * OW
+        gz = gz.contiguous()
+        dy = torch.empty((M, Cout), dtype=torch.float32, device=dev)
+        gres = torch.empty((M, Cout), dtype=torch.float32, device=dev) if (has_res and relu) else None
+        coef = torch.empty((3, Cout), dtype=torch.float32, device=dev)
+        nb = lib().bn_workspace_bytes(M, Cout)
+        ws = _ws.get(nb, dev)
+        gslot, bslot = getattr(gamma, "_gslot", None), getattr(beta, "_gslot", None)
+        dgamma = gslot if gslot is not None else torch.empty_like(gamma)
+        dbeta = bslot if bslot is not None else torch.empty_like(beta)
+        acc = 1 if gslot is not None else 0
+        lib().bn_train_bwd(_p(gz), _p(z), _p(y), _p(gamma), _p(stats), _p(dy), _p(gres), _p(dgamma), _p(dbeta), _p(coef), M,
+                           Cout, 1 if relu else 0, acc, _p(ws), nb, _stream())
+        if gslot is not None:
+            gamma._stil_touched = True
+            beta._stil_touched = True
+        if has_res:
+            dres = (gres if relu else gz).view(Nb, OH, OW, Cout)
+        else:
+            dres = None
+        dx = None
+        if is_stem:
+            Kp = stem[3]
+            Kreal = w.shape[1] * k * k
+            dw = _grad_into(w, lambda dst, a: wgrad_tn(dy, x, dst, M, Cout, Kp, Kdst=Kreal, accumulate=a))
+        else:
+            _, H, W_, Cin = x.shape
+            if ctx.needs_input_grad[0]:
+                if k == 1 and stride == 1:
+                    wd = transpose(w.reshape(Cout, Cin))  # [Cin, Cout]
+                    dx = gemm_nt(dy, wd, M, Cin, Cout).view(Nb, H, W_, Cin)
+                else:
+                    wd = torch.empty((Cin, k * k * Cout), dtype=torch.float32, device=dev)
+                    lib().conv_weight_layout(_p(w), None, _p(wd), Cout, Cin, k, k, _stream())
+                    g2 = (OH, OW, Cout, H, W_, k, k, stride, pad, 1)
+                    dx = gemm_nt(dy, wd, Nb * H * W_, Cin, k * k * Cout, geom=g2).view(Nb, H, W_, Cin)
+            gw = geom[:9]
+            dw = _grad_into(w, lambda dst, a: wgrad_tn(dy, x, dst, M, Cout, k * k * Cin, geom=gw, accumulate=a))
+        return (dx, dw, (None if gslot is not None else dgamma), (None if bslot is not None else dbeta), None, None, None,
+                dres, None, None, None, None, None)
+
+
+def conv_bn_eval(x, w, gamma, beta, rmean, rvar, resid, k, stride, pad, relu, stem=None):
+    """Teacher path: eval-mode BN folded into the conv epilogue (no grad)."""
+    Cout = w.shape[0]
+    dev = x.device
+    ab = torch.empty((2, Cout), dtype=torch.float32, device=dev)
+    lib().bn_eval_affine(_p(gamma), _p(beta), _p(rmean), _p(rvar), _p(ab), Cout, 1e-5, _stream())
+    if stem is not None:
+        Nb, OH, OW, Kp, wpad = stem
+        M = Nb * OH * OW
+        z = gemm_nt(x, wpad, M, Cout, Kp, scale=ab[0], shift=ab[1], resid=resid, act=1 if relu else 0)
+        return z.view(Nb, OH, OW, Cout)
+    Nb, H, W_, Cin = x.shape
+    OH = (H + 2 * pad - k) // stride + 1
+    OW = (W_ + 2 * pad - k) // stride + 1
+    M = Nb * OH * OW
+    if k == 1:
+        wf = w.reshape(Cout, Cin)
+    else:
+        wf = torch.empty((Cout, k * k * Cin), dtype=torch.float32, device=dev)
+        lib().conv_weight_layout(_p(w), _p(wf), None, Cout, Cin, k, k, _stream())
+    z = gemm_nt(x, wf, M, Cout, k * k * Cin, geom=_conv_geom_fwd(H, W_, Cin, OH, OW, k, stride, pad), scale=ab[0],
+                shift=ab[1], resid=resid, act=1 if relu else 0)
+    return z.view(Nb, OH, OW, Cout)
+
+
+def im2col_stem(x_nchw, k, stride, pad):
+    """NCHW image -> (col [M, Kp], (N, OH, OW, Kp)); K padded to a multiple of 16."""
+    _chk(x_nchw)
+    Nb, Cin, H, W_ = x_nchw.shape
+    OH = (H + 2 * pad - k) // stride + 1
+    OW = (W_ + 2 * pad - k) // stride + 1
+    Kp = ((Cin * k * k + 15) // 16) * 16
+    col = torch.empty((Nb * OH * OW, Kp), dtype=torch.float32, device=x_nchw.device)
+    lib().im2col_nchw(_p(x_nchw), _p(col), Nb, Cin, H, W_, OH, OW, k, k, stride, pad, Kp, _stream())
+    return col, (Nb, OH, OW, Kp)
+
+
+def pad_stem_weight(w, Kp):
+    Cout = w.shape[0]
+    wp = torch.zeros((Cout, Kp), dtype=torch.float32, device=w.device)
+    wp[:, : w[0].numel()] = w.detach().reshape(Cout, -1)
+    return wp
+
+
+class MaxPoolFn(torch.autograd.Function):
+    """nn.MaxPool2d(3, 2, 1) on NHWC (models/resnets.py:252)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        Nb, H, W_, C = x.shape
+        OH, OW = (H + 2 - 3) // 2 + 1, (W_ + 2 - 3) // 2 + 1
+        y = torch.empty((Nb, OH, OW, C), dtype=torch.float32, device=x.device)
+        idx = torch.empty((Nb, OH, OW, C), dtype=torch.uint8, device=x.device)
+        lib().maxpool3x3s2_fwd(_p(x), _p(y), _p(idx), Nb, H, W_, C, OH, OW, _stream())
+        ctx.save_for_backward(idx)
+        ctx.shape = (Nb, H, W_, C, OH, OW)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (idx,) = ctx.saved_tensors
+        Nb, H, W_, C, OH, OW = ctx.shape
+        gy = gy.contiguous()
+        dx = torch.empty((Nb, H, W_, C), dtype=torch.float32, device=gy.device)
+        lib().maxpool3x3s2_bwd(_p(gy), _p(idx), _p(dx), Nb, H, W_, C, OH, OW, _stream())
+        return dx
+
+
+# ------------------------------------------------------------------------------------------ transformer pieces
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        _chk(x, gamma, beta)
+        D = x.shape[-1]
+        rows = x.numel() // D
+        y = torch.empty_like(x)
+        mr = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+        lib().layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(mr), rows, D, 1e-5, _stream())
+        ctx.save_for_backward(x, gamma, beta, mr)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, beta, mr = ctx.saved_tensors
+        D = x.shape[-1]
+        rows = x.numel() // D
+        gy = gy.contiguous()
+        dx = torch.empty_like(x)
+        nb = lib().layernorm_bwd_workspace_bytes(rows, D)
+        ws = _ws.get(nb, x.device)
+        gslot, bslot = getattr(gamma, "_gslot", None), getattr(beta, "_gslot", None)
+        dg = gslot if gslot is not None else torch.empty_like(gamma)
+        db = bslot if bslot is not None else torch.empty_like(beta)
+        lib().layernorm_bwd(_p(gy), _p(x), _p(gamma), _p(mr), _p(dx), _p(dg), _p(db), rows, D, 1 if gslot is not None else 0,
+                            _p(ws), nb, _stream())
+        if gslot is not None:
+            gamma._stil_touched = True
+            beta._stil_touched = True
+            return dx, None, None
+        return dx, dg, db
+
+
+def layernorm(x, gamma, beta):
+    return LayerNormFn.apply(x, gamma, beta)
+
+
+class AttentionFn(torch.autograd.Function):
+    """softmax(q k^T * scale) (dropout) v for a list of (q_off, Sq, kv_off, Skv) token windows sharing one qkv buffer.
+
+    qkv: [B, T, 3*H*d] laid out (3, H, d) per token, exactly nn.Linear(dim, 3*dim)'s output
+    (models/Transformer.py:66, disentangle_transformer.py:54-62).  Output [B, T, H*d].
+    """
+
+    @staticmethod
+    def forward(ctx, qkv, H, windows, masks, drop_p):
+        _chk(qkv)
+        B, T, three = qkv.shape
+        d = three // (3 * H)
+        scale = d ** -0.5
+        out = torch.zeros((B, T, H * d), dtype=torch.float32, device=qkv.device)
+        probs = []
+        for wi, (qo, Sq, ko, Skv) in enumerate(windows):
+            pr = torch.empty((B, H, Sq, Skv), dtype=torch.float32, device=qkv.device)
+            mk = None if masks is None else masks[wi]
+            _chk(mk)
+            lib().attention_fwd(_p(qkv), _p(out), _p(pr), _p(mk), B, T, H, d, qo, Sq, ko, Skv, scale, drop_p, _stream())
+            probs.append(pr)
+        ctx.save_for_backward(qkv, *probs)
+        ctx.cfg = (H, d, windows, masks, drop_p, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        qkv, *probs = ctx.saved_tensors
+        H, d, windows, masks, drop_p, scale = ctx.cfg
+        B, T, _ = qkv.shape
+        gout = gout.contiguous()
+        dqkv = torch.zeros_like(qkv)
+        for wi, (qo, Sq, ko, Skv) in enumerate(windows):
+            mk = None if masks is None else masks[wi]
+            lib().attention_bwd(_p(gout), _p(qkv), _p(probs[wi]), _p(mk), _p(dqkv), B, T, H, d, qo, Sq, ko, Skv, scale,
+                                drop_p, _stream())
+        return dqkv, None, None, None, None
+
+
+def attention(qkv, H, windows, masks=None, drop_p=0.0):
+    return AttentionFn.apply(qkv, H, tuple(windows), masks, drop_p)
+
+
+class DropAddFn(torch.autograd.Function):
+    """out = resid + x * emask * rowmask * scale  (nn.Dropout, drop_path and the residual add in one pass)."""
+
+    @staticmethod
+    def forward(ctx, x, resid, emask, rmask, rowlen, scale):
+        _chk(x, resid, emask, rmask)
+        out = torch.empty_like(x)
+        lib().drop_add(_p(x), _p(resid), _p(emask), _p(rmask), _p(out), x.numel(), rowlen, scale, _stream())
+        ctx.masks = (emask, rmask, rowlen, scale)
+        ctx.has_res = resid is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        emask, rmask, rowlen, scale = ctx.masks
+        g = g.contiguous()
+        if emask is None and rmask is None and scale == 1.0:
+            dx = g
+        else:
+            dx = torch.empty_like(g)
+            lib().drop_add(_p(g), None, _p(emask), _p(rmask), _p(dx), g.numel(), rowlen, scale, _stream())
+        return dx, (g if ctx.has_res else None), None, None, None, None
+
+
+def drop_add(x, resid=None, emask=None, rmask=None, rowlen=1, scale=1.0):
+    if resid is None and emask is None and rmask is None and scale == 1.0:
+        return x
+    return DropAddFn.apply(x, resid, emask, rmask, rowlen, float(scale))
+
+
+class TabEmbedFn(torch.autograd.Function):
+    """TabularTransformerEncoder.embedding before the LayerNorm (models/Transformer.py:240-256)."""
+
+    @staticmethod
+    def forward(ctx, x, cat_emb, con_w, con_b, cls, colemb, offs, rowcol, ncat):
+        _chk(x, cat_emb, con_w, con_b, cls, colemb)
+        B, ncols = x.shape
+        D = cls.shape[-1]
+        h = torch.empty((B, ncols + 1, D), dtype=torch.float32, device=x.device)
+        lib().tab_embed_fwd(_p(x), _p(offs), _p(cat_emb), _p(con_w), _p(con_b), _p(cls), _p(colemb), _p(h), B, ncols, ncat, D,
+                            _stream())
+        ctx.save_for_backward(x, cat_emb, con_w, con_b, cls, colemb)
+        ctx.cfg = (offs, rowcol, ncat)
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        x, cat_emb, con_w, con_b, cls, colemb = ctx.saved_tensors
+        offs, rowcol, ncat = ctx.cfg
+        B, ncols = x.shape
+        D = cls.shape[-1]
+        g = g.contiguous()
+        params = [cat_emb, con_w, con_b, cls, colemb]
+        slots = [getattr(p_, "_gslot", None) if p_ is not None else None for p_ in params]
+        use_slab = slots[3] is not None
+        outs = [(s if use_slab else (torch.zeros_like(p_) if p_ is not None else None)) for p_, s in zip(params, slots)]
+        nb = lib().tab_embed_bwd_workspace_bytes(ncols, D)
+        ws = _ws.get(nb, x.device)
+        nrows = 0 if cat_emb is None else cat_emb.shape[0]
+        lib().tab_embed_bwd(_p(g), _p(x), _p(offs), _p(rowcol), nrows if ncat else 0, _p(outs[0]), _p(outs[1]), _p(outs[2]),
+                            _p(outs[3]), _p(outs[4]), B, ncols, ncat, D, 1 if use_slab else 0, _p(ws), nb, _stream())
+        if use_slab:
+            for p_ in params:
+                if p_ is not None:
+                    p_._stil_touched = True
+            return (None,) * 9
+        return (None, outs[0], outs[1], outs[2], outs[3], outs[4], None, None, None)
+
+
+class TokMeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        B, T, D = x.shape
+        y = torch.empty((B, D), dtype=torch.float32, device=x.device)
+        lib().tokmean_fwd(_p(x), _p(y), B, T, D, _stream())
+        ctx.shape = (B, T, D)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        B, T, D = ctx.shape
+        g = g.contiguous()
+        dx = torch.empty((B, T, D), dtype=torch.float32, device=g.device)
+        lib().tokmean_bwd(_p(g), _p(dx), B, T, D, _stream())
+        return dx
+
+
+def tokmean(x):
+    return TokMeanFn.apply(x.contiguous())
+
+
+# ------------------------------------------------------------------------------------------ losses
+class L2NormFn(torch.autograd.Function):
+    """F.normalize(x, dim=1) (STiLModel.py:185-191, utils/clip_loss.py:29-30)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        R, D = x.shape
+        y = torch.empty_like(x)
+        n = torch.empty((R,), dtype=torch.float32, device=x.device)
+        lib().l2norm_fwd(_p(x), _p(y), _p(n), R, D, _stream())
+        ctx.save_for_backward(y, n)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, n = ctx.saved_tensors
+        g = g.contiguous()
+        dx = torch.empty_like(g)
+        lib().l2norm_bwd(_p(g), _p(y), _p(n), _p(dx), y.shape[0], y.shape[1], _stream())
+        return dx
+
+
+def l2norm(x):
+    return L2NormFn.apply(x.contiguous())
+
+
+def _scale_by(unit, g, c=1.0):
+    out = torch.empty_like(unit)
+    lib().scale_dev(_p(unit), _p(g.contiguous()), float(c), _p(out), unit.numel(), _stream())
+    return out
+
+
+class CEHardFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss() (mean) -- STiLModel.py:284."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        _chk(logits, labels)
+        R, K = logits.shape
+        rl = torch.empty((R,), dtype=torch.float32, device=logits.device)
+        dz = torch.empty_like(logits)
+        lib().ce_hard(_p(logits), K, _p(labels), _p(rl), _p(dz), K, R, K, 1.0 / R, _stream())
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        lib().reduce_sum(_p(rl), R, 1.0 / R, _p(loss), 0, _stream())
+        ctx.save_for_backward(dz)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dz,) = ctx.saved_tensors
+        return _scale_by(dz, g), None
+
+
+class CESoftFn(torch.autograd.Function):
+    """(F.cross_entropy(logits, q, reduction='none') * w).mean() -- STiLModel.py:301-303."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, row_w):
+        _chk(logits, targets, row_w)
+        R, K = logits.shape
+        rl = torch.empty((R,), dtype=torch.float32, device=logits.device)
+        dz = torch.empty_like(logits)
+        lib().ce_soft(_p(logits), K, _p(targets), K, _p(row_w), _p(rl), _p(dz), K, R, K, 1.0 / R, _stream())
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        lib().reduce_sum(_p(rl), R, 1.0 / R, _p(loss), 0, _stream())
+        ctx.save_for_backward(dz)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dz,) = ctx.saved_tensors
+        return _scale_by(dz, g), None, None
+
+
+class ClipFromLogitsFn(torch.autograd.Function):
+    """lambda_0 CE(Z, diag) + (1-lambda_0) CE(Z^T, diag)  (utils/clip_loss.py:35-38)."""
+
+    @staticmethod
+    def forward(ctx, Z, lam0):
+        _chk(Z)
+        B = Z.shape[0]
+        lse = torch.empty((2, B), dtype=torch.float32, device=Z.device)
+        terms = torch.empty((B,), dtype=torch.float32, device=Z.device)
+        loss = torch.empty((), dtype=torch.float32, device=Z.device)
+        lib().clip_fwd(_p(Z), _p(lse), _p(terms), _p(loss), B, lam0, 1.0 - lam0, _stream())
+        ctx.save_for_backward(Z, lse)
+        ctx.lam0 = lam0
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        Z, lse = ctx.saved_tensors
+        dZ = torch.empty_like(Z)
+        lib().clip_bwd(_p(Z), _p(lse), _p(g.contiguous()), _p(dZ), Z.shape[0], ctx.lam0, 1.0 - ctx.lam0, _stream())
+        return dZ, None
+
+
+def clip_loss(f0, f1, T, lam0):
+    """CLIPLoss.forward (utils/clip_loss.py:27-39). Returns (loss, logits)."""
+    n0, n1 = l2norm(f0), l2norm(f1)
+    Z = MatmulNTFn.apply(n0, n1, 1.0 / T)
+    return ClipFromLogitsFn.apply(Z, float(lam0)), Z
+
+
+class ClubFn(torch.autograd.Function):
+    """CLUBMean.forward + learning_loss given mu = p_mu(x)  (club.py:107-130), closed form over the batch."""
+
+    @staticmethod
+    def forward(ctx, mu, y):
+        _chk(mu, y)
+        R, D = y.shape
+        dev = y.device
+        ybar = torch.empty((D,), dtype=torch.float32, device=dev)
+        mubar = torch.empty((D,), dtype=torch.float32, device=dev)
+        colsum(y, ybar, R, D, scale=1.0 / R)
+        colsum(mu, mubar, R, D, scale=1.0 / R)
+        tmp = torch.empty((2, R), dtype=torch.float32, device=dev)
+        out2 = torch.empty((2,), dtype=torch.float32, device=dev)
+        lib().club_fwd(_p(mu), _p(y), _p(ybar), _p(tmp), _p(out2), R, D, _stream())
+        ctx.save_for_backward(mu, y, ybar, mubar)
+        return out2[0], out2[1]
+
+    @staticmethod
+    def backward(ctx, gc, ge):
+        mu, y, ybar, mubar = ctx.saved_tensors
+        R, D = y.shape
+        dmu = torch.empty_like(mu)
+        dy = torch.empty_like(y)
+        lib().club_bwd(_p(mu), _p(y), _p(ybar), _p(mubar), _p(gc.contiguous()), _p(ge.contiguous()), _p(dmu), _p(dy), R, D,
+                       _stream())
+        return dmu, dy
+
+
+class ProtoLossFn(torch.autograd.Function):
+    """PrototypeLoss.forward (utils/prototype_loss.py:24-40); hard label / confidence precomputed per row."""
+
+    @staticmethod
+    def forward(ctx, feat, prototypes, hard, conf, T):
+        _chk(feat, prototypes, hard, conf)
+        R, Dp = feat.shape
+        K = prototypes.shape[0]
+        rl = torch.empty((R,), dtype=torch.float32, device=feat.device)
+        df = torch.empty_like(feat)
+        lib().proto_loss(_p(feat), _p(prototypes), _p(hard), _p(conf), _p(rl), _p(df), R, K, Dp, T, _stream())
+        loss = torch.empty((), dtype=torch.float32, device=feat.device)
+        lib().reduce_sum(_p(rl), R, 1.0 / R, _p(loss), 0, _stream())
+        ctx.save_for_backward(df)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (df,) = ctx.saved_tensors
+        return _scale_by(df, g), None, None, None, None
+
+
+@torch.no_grad()
+def cgpl_pgls(zm, zi, zt, feat_u, prototypes, mask_random, rate_pseudo, T, th, use_pseudo, want_orig=False):
+    """CGPL case partition + PGLS smoothing (STiLModel.py:262-299,317-320) in one launch."""
+    _chk(zm, zi, zt, feat_u, prototypes, mask_random)
+    Bu, K = zm.shape
+    Dp = feat_u.shape[1]
+    dev = zm.device
+    pl = torch.empty((Bu, K), dtype=torch.float32, device=dev)
+    po = torch.empty((Bu, K), dtype=torch.float32, device=dev) if want_orig else None
+    pred = torch.empty((Bu, K), dtype=torch.float32, device=dev)
+    flags = torch.empty((Bu, 4), dtype=torch.uint8, device=dev)
+    hard = torch.empty((Bu,), dtype=torch.int32, device=dev)
+    w3 = torch.empty((3, Bu), dtype=torch.float32, device=dev)
+    lib().cgpl_pgls(_p(zm), _p(zi), _p(zt), K, _p(feat_u), _p(prototypes), _p(mask_random), _p(pl), _p(po), _p(pred),
+                    _p(flags), _p(hard), _p(w3), Bu, K, Dp, rate_pseudo, T, th, 1 if use_pseudo else 0, _stream())
+    return pl, po, pred, flags, hard, w3

@@ -1,0 +1,327 @@
+"""STiLModel: drop-in for the reference's LightningModule (models/Disentangle/STiLModel.py:29-588).
+
+Same constructor (`STiLModel(hparams)`), same hooks (`training_step(batch, batch_idx) -> loss`,
+`training_epoch_end`, `validation_step`, `test_step`, `configure_optimizers`), same state_dict keys,
+same `batch` layout.  pytorch-lightning is optional: when it is importable the class
+derives from pl.LightningModule, otherwise from nn.Module with a minimal `log`/`current_epoch` shim and
+`stil_tta_amd.driver` runs the zero_grad -> training_step -> backward -> step loop.
+
+All arithmetic runs in the HIP kernels of libstil_hip.so (ops.py); there is no CPU fallback.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.distributed as dist
+
+from . import ops
+from .flat import FlatState, StilAdam
+from .modules import DisCoAttentionBackbone, fuse_mi_masks, random_mi_masks
+from .ops import _p, _stream
+from ._lib import lib
+
+try:  # optional
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+    _HAVE_PL = True
+except Exception:  # pragma: no cover - pl is absent in the build image
+    _Base = nn.Module
+    _HAVE_PL = False
+
+_DEFAULTS = dict(
+    model="resnet50", embedding_dim=2048, img_size=128, num_classes=286, target="dvm",
+    tabular_embedding_dim=512, tabular_transformer_num_layers=4, embedding_dropout=0.0, drop_rate=0.0,
+    multimodal_embedding_dim=512, multimodal_transformer_num_layers=1, projection_dim=128, temperature=0.1,
+    lambda_0=0.5, alpha=0.2, beta=3.0, gamma=0.5, rate_pt=1.0, rate_uce=0.2, th1=0.9, th2=0.95, th_contrast=0.8,
+    start_epoch=35, rate_pseudo=0.9, use_ema=True, eman=True, ema_momentum=0.996, DA=False, repeat_ratio=1.0,
+    batch_size=512, lr_eval=1e-4, weight_decay_eval=0.0, scheduler="anneal", warmup_epochs=10, max_epochs=500,
+    checkpoint=None, pretrained_model="TIP", finetune_strategy="trainable", pretrain=False, logdir=None,
+    mi_dropout=True, seed=2022,
+)
+
+
+def _as_namespace(hp) -> SimpleNamespace:
+    d = dict(_DEFAULTS)
+    if isinstance(hp, dict):
+        d.update(hp)
+    else:
+        try:
+            d.update({k: hp[k] for k in hp.keys()})  # DictConfig / AttributeDict
+        except Exception:
+            d.update(vars(hp))
+    if d.get("repeat_ratio") in (None, 0):
+        d["repeat_ratio"] = 1.0
+    return SimpleNamespace(**d)
+
+
+class SimCLRProjectionHead(nn.Module):
+    """lightly==1.2.22 SimCLRProjectionHead restated: Linear -> ReLU -> Linear under `.layers` (unpinned)."""
+
+    def __init__(self, i, h, o):
+        super().__init__()
+        self.layers = nn.Sequential(nn.Linear(i, h), nn.ReLU(), nn.Linear(h, o))
+
+    def run(self, x):
+        return ops.linear(ops.linear(x, self.layers[0].weight, self.layers[0].bias, act=1), self.layers[2].weight, self.layers[2].bias)
+
+
+class _LinearHead(nn.Linear):
+    def run(self, x):
+        return ops.linear(x, self.weight, self.bias)
+
+
+class CLUBMean(nn.Module):  # models/Disentangle/utils/club.py:88-130
+    def __init__(self, x_dim, y_dim, hidden_size=512):
+        super().__init__()
+        self.p_mu = nn.Sequential(nn.Linear(x_dim, hidden_size), nn.ReLU(), nn.Linear(hidden_size, y_dim))
+
+    def both(self, x, y):
+        """-> (forward(x, y), learning_loss(x, y)) sharing one p_mu evaluation."""
+        mu = ops.linear(ops.linear(x, self.p_mu[0].weight, self.p_mu[0].bias, act=1), self.p_mu[2].weight, self.p_mu[2].bias)
+        return ops.ClubFn.apply(mu, y.contiguous())
+
+
+class STiLModel(_Base):
+    def __init__(self, hparams):
+        super().__init__()
+        hp = _as_namespace(hparams)
+        if _HAVE_PL:
+            self.save_hyperparameters(vars(hp))
+        else:
+            self.hparams = hp
+            self._epoch = 0
+            self.logged: Dict[str, torch.Tensor] = {}
+        self.hp = hp
+        fl = getattr(hp, "field_lengths", None)
+        if fl is None:
+            fl = torch.load(hp.field_lengths_tabular)  # STiLModel_backbone.py:97
+        self.field_lengths = [int(v) for v in fl]
+        C, Dp = hp.multimodal_embedding_dim, hp.projection_dim
+        self.model = DisCoAttentionBackbone(hp, self.field_lengths)
+        self.projector_multimodal = SimCLRProjectionHead(C * 3, C * 3, Dp)
+        if hp.target == "dvm":  # STiLModel.py:57-63
+            self.projector_imaging = _LinearHead(C, Dp)
+            self.projector_tabular = _LinearHead(C, Dp)
+        else:
+            self.projector_imaging = SimCLRProjectionHead(C, C, Dp)
+            self.projector_tabular = SimCLRProjectionHead(C, C, Dp)
+        self.CLUB_imaging = CLUBMean(C, C)
+        self.CLUB_tabular = CLUBMean(C, C)
+        self.use_ema = bool(hp.use_ema)
+        if self.use_ema:
+            self.ema = DisCoAttentionBackbone(hp, self.field_lengths)
+            self.ema.load_state_dict(self.model.state_dict())
+            for p in self.ema.parameters():
+                p.requires_grad = False
+        self.register_buffer("prototypes", torch.zeros(hp.num_classes, Dp))
+        self.register_buffer("prototypes_sum", torch.zeros(hp.num_classes, Dp))
+        self.register_buffer("prototypes_count_sum", torch.zeros(hp.num_classes, 1))
+        if hp.DA:
+            self.DA_len = 256
+            self.register_buffer("DA_queue", torch.zeros(self.DA_len, hp.num_classes))
+            self.register_buffer("DA_ptr", torch.zeros(1, dtype=torch.long))
+        self.best_val_score = 0
+        self.flat: Optional[FlatState] = None
+        self._rng_offset = 0
+        self.last: Dict[str, torch.Tensor] = {}
+        if hp.checkpoint:
+            self._load_tip_checkpoint(hp)
+
+    # ------------------------------------------------------------------ plumbing
+    if not _HAVE_PL:
+        @property
+        def current_epoch(self):
+            return self._epoch
+
+        @current_epoch.setter
+        def current_epoch(self, v):
+            self._epoch = int(v)
+
+        def log(self, name, value, **kw):
+            self.logged[name] = value
+
+        def print(self, *a, **k):
+            print(*a, **k)
+
+    def _load_tip_checkpoint(self, hp):
+        """STiLModel_backbone.py:69-90,108-115: load encoder_imaging.* / encoder_tabular.* from a TIP checkpoint."""
+        ck = torch.load(hp.checkpoint, map_location="cpu")
+        sd = ck["state_dict"]
+        for mod, prefix in ((self.model.encoder_imaging, "encoder_imaging."), (self.model.encoder_tabular, "encoder_tabular.")):
+            sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix) and "projection_head" not in k and "prototypes" not in k}
+            mod.load_state_dict(sub, strict=True)
+            if hp.finetune_strategy == "frozen":
+                for p in mod.parameters():
+                    p.requires_grad = False
+        if self.use_ema:
+            self.ema.load_state_dict(self.model.state_dict())
+
+    def setup_device(self, device=None):
+        """Move to the GPU and carve the flat parameter / gradient / Adam / EMA slabs (idempotent)."""
+        if self.flat is not None:
+            return self
+        if lib().device_count() < 1:
+            raise RuntimeError("stil_tta_amd: no HIP device visible; the training step has no CPU path")
+        device = torch.device(device or "cuda")
+        nn.Module.to(self, device)
+        teacher = self.ema if self.use_ema else DisCoAttentionBackbone(self.hp, self.field_lengths).to(device)
+        self.flat = FlatState(self.model, teacher, [self.projector_imaging, self.projector_tabular, self.projector_multimodal,
+                                                    self.CLUB_imaging, self.CLUB_tabular], device)
+        return self
+
+    def configure_optimizers(self):
+        """STiLModel.py:557-577: Adam(lr_eval, weight_decay_eval) over model + projectors + CLUBs (EMA excluded)."""
+        self.setup_device(self.prototypes.device if self.prototypes.is_cuda else None)
+        opt = StilAdam(self.flat, lr=self.hp.lr_eval, weight_decay=self.hp.weight_decay_eval)
+        if self.hp.scheduler == "anneal":
+            from .driver import anneal_lambda
+            sched = torch.optim.lr_scheduler.LambdaLR(opt, anneal_lambda(self.hp.warmup_epochs, self.hp.max_epochs))
+            return {"optimizer": opt, "lr_scheduler": sched}
+        return {"optimizer": opt}
+
+    def project_3features(self, feat_m=None, feat_i=None, feat_t=None):  # STiLModel.py:182-192
+        fm = ops.l2norm(self.projector_multimodal.run(feat_m)) if feat_m is not None else None
+        fi = ops.l2norm(self.projector_imaging.run(feat_i)) if feat_i is not None else None
+        ft = ops.l2norm(self.projector_tabular.run(feat_t)) if feat_t is not None else None
+        return fm, fi, ft
+
+    def _mi_masks(self, B, mi_masks):
+        if mi_masks is not None:  # injected (parity tests): oracle layout -> fused layout
+            return {li: fuse_mi_masks(m, self.prototypes.device) for li, m in mi_masks.items()}
+        if not self.hp.mi_dropout:
+            return None
+        Ni = (self._img_tokens)
+        Nt = len(self.field_lengths)
+        C = self.hp.multimodal_embedding_dim
+        out = {}
+        for li in range(self.hp.multimodal_transformer_num_layers):
+            out[li] = random_mi_masks(B, Ni, Nt, C, 4, 0.1, self.hp.seed, self._rng_offset, self.prototypes.device)
+            self._rng_offset += 4 * B * (1 + Ni + Nt) * (C + 4 * (1 + Ni + Nt))
+        return out
+
+    # ------------------------------------------------------------------ the hot path
+    def training_step(self, batch, _=None, mask_random: Optional[torch.Tensor] = None, mi_masks=None):
+        """STiLModel.training_step (STiLModel.py:228-386).  `mask_random` / `mi_masks` optionally inject the
+        step's randomness (parity tests); otherwise it is drawn on the device."""
+        hp = self.hp
+        self.setup_device()
+        dev = self.prototypes.device
+        current_epoch = self.current_epoch
+        im_l, tab_l, y_l = batch["l"][0][1], batch["l"][1][1], batch["l"][2]
+        im_u, tab_u, y_u = batch["u"][0][1], batch["u"][1][1], batch["u"][2]
+        B_l, B_u = len(y_l), len(y_u)
+        B = B_l + B_u
+        x_img = torch.cat((im_l, im_u)).to(dev, torch.float32).contiguous()
+        x_tab = torch.cat((tab_l, tab_u)).to(dev, torch.float32).contiguous()
+        y_l = y_l.to(dev)
+        self._img_tokens = (x_img.shape[-1] // 32) * (x_img.shape[-2] // 32)
+        K, T, th = hp.num_classes, float(hp.temperature), float(hp.th1)
+        use_pseudo = current_epoch > hp.start_epoch
+        cache = {}
+
+        masks = self._mi_masks(B, mi_masks)
+        s = self.model.forward_all((x_img, x_tab), train=True, mi_masks=masks, cache=cache)
+        y_m, y_i, y_t, si_e, si_m, ai, st_e, st_m, at, xc = s
+        feat_m, feat_i, feat_t = self.project_3features(torch.cat((si_e, xc, st_e), dim=1), ai, at)
+
+        with torch.no_grad():
+            if self.use_ema:
+                self.flat.ema_update(hp.ema_momentum, bool(hp.eman))
+                t = self.ema.forward_all((x_img, x_tab), train=False, cache=cache)
+                feat_m_e, _, _ = self.project_3features(torch.cat((t[3], t[9], t[6]), dim=1))
+                ym_e, yi_e, yt_e = t[0], t[1], t[2]
+            else:
+                ym_e, yi_e, yt_e, feat_m_e = y_m.detach(), y_i.detach(), y_t.detach(), feat_m.detach()
+            if mask_random is None:
+                mask_random = ops.rng_mask((B_u,), 0.5, hp.seed + 1, self._rng_offset, dev)
+                self._rng_offset += B_u
+            else:
+                mask_random = mask_random.to(device=dev, dtype=torch.uint8).contiguous()
+            prototypes = self.prototypes.clone()
+            if hp.DA:
+                raise NotImplementedError("distribution alignment (DA: True) is not built yet; the reference default is False")
+            pl_, po_, pred, flags, hard_u, w3 = ops.cgpl_pgls(
+                ym_e[B_l:], yi_e[B_l:], yt_e[B_l:], feat_m_e[B_l:].contiguous(), prototypes, mask_random, float(hp.rate_pseudo), T, th,
+                use_pseudo, want_orig=True)
+            # hard label / confidence of pseudo_label_all = cat(one_hot(y_l), prediction)  (STiLModel.py:321)
+            hard = torch.cat((y_l.to(torch.int32), hard_u))
+            conf = torch.cat((torch.ones(B_l, dtype=torch.uint8, device=dev), flags[:, 2].contiguous()))
+
+        # ---- losses (STiLModel.py:284-345)
+        ce = ops.CEHardFn.apply
+        loss_ce = ce(y_m[:B_l].contiguous(), y_l) + ce(y_i[:B_l].contiguous(), y_l) + ce(y_t[:B_l].contiguous(), y_l)
+        loss_m_u = ops.CESoftFn.apply(y_m[B_l:].contiguous(), pl_, w3[0])
+        loss_i_u = ops.CESoftFn.apply(y_i[B_l:].contiguous(), pl_, w3[1])
+        loss_t_u = ops.CESoftFn.apply(y_t[B_l:].contiguous(), pl_, w3[2])
+        loss_itc, itc_logits = ops.clip_loss(feat_i, feat_t, T, float(hp.lambda_0))
+        club_i, est_i = self.CLUB_imaging.both(si_m, ai)
+        club_t, est_t = self.CLUB_tabular.both(st_m, at)
+        loss_pt = ops.ProtoLossFn.apply(feat_m, prototypes, hard, conf, T)
+        loss = hp.alpha * loss_ce + hp.beta * loss_itc + hp.gamma * (club_i + est_i + club_t + est_t)
+        if use_pseudo:
+            loss = loss + hp.rate_pt * loss_pt + hp.rate_uce * (loss_m_u + loss_i_u + loss_t_u)
+
+        # ---- prototype accumulation from TEACHER features (STiLModel.py:374-381)
+        with torch.no_grad():
+            cs = torch.empty((K, hp.projection_dim + 1), dtype=torch.float32, device=dev)
+            lib().proto_accum(_p(feat_m_e), _p(hard), _p(conf), _p(cs), B, B_l, K, hp.projection_dim, float(hp.repeat_ratio), _stream())
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                dist.all_reduce(cs, op=dist.ReduceOp.SUM)  # ONE fused [K, Dp+1] collective instead of the reference's two
+            lib().proto_add(_p(cs), _p(self.prototypes_sum), _p(self.prototypes_count_sum), K, hp.projection_dim, _stream())
+
+        bs = B
+        for name, v in (("CEloss", loss_ce), ("CEloss_unlabelled_m", loss_m_u), ("CEloss_unlabelled_i", loss_i_u),
+                        ("CEloss_unlabelled_t", loss_t_u), ("ITCloss", loss_itc), ("CLUBloss_imaging", club_i),
+                        ("CLUBloss_imaging_est", est_i), ("CLUBloss_tabular", club_t), ("CLUBloss_tabular_est", est_t),
+                        ("PTloss", loss_itc), ("loss", loss)):  # "PTloss" logs loss_itc in the reference too (STiLModel.py:340)
+            self.log(f"multimodal.train.{name}", v.detach(), on_epoch=True, on_step=False, batch_size=bs)
+        self.last = dict(
+            loss=loss, loss_ce=loss_ce, loss_itc=loss_itc, loss_club_i=club_i, loss_club_i_est=est_i, loss_club_t=club_t,
+            loss_club_t_est=est_t, loss_pt=loss_pt, loss_m_u=loss_m_u, loss_i_u=loss_i_u, loss_t_u=loss_t_u,
+            y_hat_m=y_m, y_hat_i=y_i, y_hat_t=y_t, x_si_enhance=si_e, x_si=si_m, x_ai=ai, x_st_enhance=st_e, x_st=st_m,
+            x_at=at, x_c=xc, feat_m=feat_m, feat_i=feat_i, feat_t=feat_t, y_hat_m_e=ym_e, y_hat_i_e=yi_e, y_hat_t_e=yt_e,
+            feat_m_e=feat_m_e, pseudo_label_orig=po_, pseudo_label=pl_, prediction=pred, flags=flags, w3=w3,
+            mask_random=mask_random, class_sum=cs[:, :-1], class_count=cs[:, -1:], itc_logits=itc_logits)
+        return loss
+
+    def training_epoch_end(self, _=None):
+        """STiLModel.py:389-421: prototypes <- sum / count (every class needs a confident sample), zero accumulators."""
+        K, Dp = self.hp.num_classes, self.hp.projection_dim
+        bad = torch.zeros(1, dtype=torch.int32, device=self.prototypes.device)
+        lib().proto_commit(_p(self.prototypes), _p(self.prototypes_sum), _p(self.prototypes_count_sum), _p(bad), K, Dp, _stream())
+        assert int(bad.item()) == 0, "a class received no confident sample this epoch (STiLModel.py:412)"
+        self.prototypes_sum.zero_()
+        self.prototypes_count_sum.zero_()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.barrier()
+
+    # ------------------------------------------------------------------ inference-side hooks
+    @torch.no_grad()
+    def validation_step(self, batch, _=None):
+        """STiLModel.py:424-474 (losses only; torchmetrics bookkeeping is left to the caller)."""
+        x, y = batch
+        self.setup_device()
+        dev = self.prototypes.device
+        o = self.model.forward_all((x[0].to(dev, torch.float32).contiguous(), x[1].to(dev, torch.float32).contiguous()), train=False)
+        y_hat, _, _, si_e, si_m, ai, st_e, st_m, at, xc = o
+        _, fi, ft = self.project_3features(None, ai, at)
+        loss_itc, _ = ops.clip_loss(fi, ft, float(self.hp.temperature), float(self.hp.lambda_0))
+        ci, ei = self.CLUB_imaging.both(si_m, ai)
+        ct, et = self.CLUB_tabular.both(st_m, at)
+        loss_ce = ops.CEHardFn.apply(y_hat.contiguous(), y.to(dev))
+        loss = self.hp.alpha * loss_ce + self.hp.beta * loss_itc + self.hp.gamma * (ci + ei + ct + et)
+        self.log("multimodal.val.loss", loss)
+        return loss
+
+    @torch.no_grad()
+    def test_step(self, batch, _=None):
+        """STiLModel.py:517-533: returns softmax(y_hat) (column 1 for binary tasks)."""
+        x, y = batch
+        self.setup_device()
+        dev = self.prototypes.device
+        y_hat = self.model.forward((x[0].to(dev, torch.float32).contiguous(), x[1].to(dev, torch.float32).contiguous()), train=False)[0]
+        p = torch.softmax(y_hat, dim=1)
+        return p[:, 1] if self.hp.num_classes == 2 else p

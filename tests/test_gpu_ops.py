@@ -1,0 +1,415 @@
+"""GPU parity of every HIP operator (through the C ABI) against plain fp32 PyTorch on the CPU
+(the same ATen ops the oracle / the reference use).  Tolerance: fp32 reassociation noise,
+|a-b| <= tol * (1 + |b| + max|b|) with tol = 2e-5 unless stated (north_star asks 1e-4)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+def close(a, b, tol=TOL, name=""):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    scale = float(b.abs().max()) if b.numel() else 0.0
+    err = (a - b).abs()
+    ok = bool((err <= tol * (1.0 + b.abs() + scale)).all())
+    assert ok, f"{name}: max err {float(err.max()):.3e} (scale {scale:.3e})"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from stil_tta_amd import ops as o
+    return o
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def nhwc(t):  # NCHW cpu -> NHWC cuda
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):  # NHWC cuda -> NCHW cpu
+    return t.detach().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (37, 7, 286), (300, 70, 48), (513, 257, 512), (1, 5, 20), (4100, 64, 64), (5000, 200, 32)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm_nt_plain(ops, M, N, K, act):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A, W, b, R = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref_pre = 0.5 * (A @ W.t()) + b + R
+    ref = ref_pre if act == 0 else (F.relu(ref_pre) if act == 1 else F.gelu(ref_pre))
+    pre = torch.empty(M, N, device="cuda")
+    out = ops.gemm_nt(dev(A), dev(W), M, N, K, bias=dev(b), resid=dev(R), pre=pre, act=act, alpha=0.5)
+    close(out, ref, name="gemm")
+    close(pre, ref_pre, name="pre")
+
+
+CONVS = [  # Cin, Cout, k, stride, pad, H
+    (64, 64, 1, 1, 0, 14), (64, 128, 1, 2, 0, 14), (32, 64, 3, 1, 1, 9), (64, 48, 3, 2, 1, 14), (16, 32, 3, 2, 1, 7),
+    (128, 256, 3, 1, 1, 4),
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,pad,H", CONVS)
+def test_conv_fwd_dgrad_wgrad(ops, Cin, Cout, k, stride, pad, H):
+    from stil_tta_amd._lib import lib
+    from stil_tta_amd.ops import _p, _stream
+    g = torch.Generator().manual_seed(Cin + Cout + k)
+    Nb, W_ = 3, H + 1
+    x = torch.randn(Nb, Cin, H, W_, generator=g, requires_grad=True)
+    w = torch.randn(Cout, Cin, k, k, generator=g, requires_grad=True)
+    y = F.conv2d(x, w, stride=stride, padding=pad)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    OH, OW = y.shape[2], y.shape[3]
+    xd, wd_ = nhwc(x.detach()), dev(w.detach())
+    wf = torch.empty(Cout, k * k * Cin, device="cuda")
+    wdg = torch.empty(Cin, k * k * Cout, device="cuda")
+    lib().conv_weight_layout(_p(wd_), _p(wf), _p(wdg), Cout, Cin, k, k, _stream())
+    M = Nb * OH * OW
+    geom = (H, W_, Cin, OH, OW, k, k, stride, pad, 0)
+    yo = ops.gemm_nt(xd, wf, M, Cout, k * k * Cin, geom=geom)
+    close(nchw(yo.view(Nb, OH, OW, Cout)), y, name="conv fwd")
+    gyd = nhwc(gy).view(M, Cout)
+    dx = ops.gemm_nt(gyd, wdg, Nb * H * W_, Cin, k * k * Cout, geom=(OH, OW, Cout, H, W_, k, k, stride, pad, 1))
+    close(nchw(dx.view(Nb, H, W_, Cin)), x.grad, name="conv dgrad")
+    dw = torch.full((Cout, Cin, k, k), 7.0, device="cuda")
+    ops.wgrad_tn(gyd, xd, dw, M, Cout, k * k * Cin, geom=geom[:9], accumulate=0)
+    close(dw, w.grad, name="conv wgrad")
+    ops.wgrad_tn(gyd, xd, dw, M, Cout, k * k * Cin, geom=geom[:9], accumulate=1)
+    close(dw, 2 * w.grad, name="conv wgrad accumulate")
+
+
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False)])
+@pytest.mark.parametrize("Cin,Cout,k,stride,pad,H", [(64, 64, 3, 1, 1, 8), (64, 128, 1, 2, 0, 8), (128, 256, 1, 1, 0, 6)])
+def test_conv_bn_act_train_and_eval(ops, Cin, Cout, k, stride, pad, H, relu, res):
+    g = torch.Generator().manual_seed(3)
+    Nb = 4
+    x = torch.randn(Nb, Cin, H, H, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * 0.1).requires_grad_()
+    gam = (0.5 + torch.rand(Cout, generator=g)).requires_grad_()
+    bet = (0.1 * torch.randn(Cout, generator=g)).requires_grad_()
+    rm, rv = 0.1 * torch.randn(Cout, generator=g), 0.5 + torch.rand(Cout, generator=g)
+    OH = (H + 2 * pad - k) // stride + 1
+    r = torch.randn(Nb, Cout, OH, OH, generator=g, requires_grad=True) if res else None
+    rm_c, rv_c = rm.clone(), rv.clone()
+    y = F.batch_norm(F.conv2d(x, w, stride=stride, padding=pad), rm_c, rv_c, gam, bet, training=True, momentum=0.1, eps=1e-5)
+    if res:
+        y = y + r
+    if relu:
+        y = F.relu(y)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd = nhwc(x.detach()).requires_grad_()
+    wd, gd, bd = dev(w.detach()).requires_grad_(), dev(gam.detach()).requires_grad_(), dev(bet.detach()).requires_grad_()
+    rmd, rvd, nbt = dev(rm), dev(rv), torch.zeros((), dtype=torch.long, device="cuda")
+    rd = nhwc(r.detach()).view(-1, Cout).requires_grad_() if res else None
+    z = ops.ConvBnActFn.apply(xd, wd, gd, bd, rmd, rvd, nbt, rd, k, stride, pad, relu, None)
+    close(nchw(z), y, name="z")
+    close(rmd, rm_c, name="running_mean")
+    close(rvd, rv_c, name="running_var")
+    assert int(nbt) == 1
+    z.backward(nhwc(gy))
+    close(nchw(xd.grad), x.grad, tol=5e-5, name="dx")
+    close(wd.grad, w.grad, tol=5e-5, name="dw")
+    close(gd.grad, gam.grad, tol=5e-5, name="dgamma")
+    close(bd.grad, bet.grad, tol=5e-5, name="dbeta")
+    if res:
+        close(nchw(rd.grad.view(Nb, OH, OH, Cout)), r.grad, name="dres")
+    # eval mode (teacher): BN folded into the conv epilogue
+    ye = F.batch_norm(F.conv2d(x.detach(), w.detach(), stride=stride, padding=pad), rm, rv, gam.detach(), bet.detach(), training=False, eps=1e-5)
+    if res:
+        ye = ye + r.detach()
+    if relu:
+        ye = F.relu(ye)
+    ze = ops.conv_bn_eval(xd.detach(), wd.detach(), gd.detach(), bd.detach(), dev(rm), dev(rv), rd.detach() if res else None, k, stride, pad, relu)
+    close(nchw(ze), ye, name="eval")
+
+
+def test_stem_and_maxpool(ops):
+    g = torch.Generator().manual_seed(5)
+    Nb, H = 3, 40
+    x = torch.rand(Nb, 3, H, H, generator=g)
+    w = (torch.randn(64, 3, 7, 7, generator=g) * 0.05).requires_grad_()
+    gam, bet = (0.5 + torch.rand(64, generator=g)).requires_grad_(), (0.1 * torch.randn(64, generator=g)).requires_grad_()
+    y = F.relu(F.batch_norm(F.conv2d(x, w, stride=2, padding=3), None, None, gam, bet, training=True, eps=1e-5))
+    yp = F.max_pool2d(y, 3, 2, 1)
+    gy = torch.randn(yp.shape, generator=g)
+    yp.backward(gy)
+    col, meta = ops.im2col_stem(dev(x), 7, 2, 3)
+    wd, gd, bd = dev(w.detach()).requires_grad_(), dev(gam.detach()).requires_grad_(), dev(bet.detach()).requires_grad_()
+    wp = ops.pad_stem_weight(wd, meta[3])
+    z = ops.ConvBnActFn.apply(col, wd, gd, bd, None, None, None, None, 7, 2, 3, True, (*meta, wp))
+    close(nchw(z), y, name="stem")
+    zp = ops.MaxPoolFn.apply(z)
+    close(nchw(zp), yp, name="maxpool")
+    zp.backward(nhwc(gy))
+    close(wd.grad, w.grad, tol=5e-5, name="stem dw")
+    close(gd.grad, gam.grad, tol=5e-5, name="stem dgamma")
+
+
+def test_maxpool_ties_after_relu(ops):
+    x = torch.zeros(1, 64, 6, 6)
+    x[0, :, 2, 3] = 1.0
+    x.requires_grad_()
+    y = F.max_pool2d(x, 3, 2, 1)
+    gy = torch.arange(y.numel(), dtype=torch.float32).reshape(y.shape)
+    y.backward(gy)
+    xd = nhwc(x.detach()).requires_grad_()
+    z = ops.MaxPoolFn.apply(xd)
+    z.backward(nhwc(gy))
+    close(nchw(z), y)
+    close(nchw(xd.grad), x.grad, name="tie routing")
+
+
+@pytest.mark.parametrize("rows,D", [(33, 512), (7, 32), (130, 96)])
+def test_layernorm(ops, rows, D):
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, D, generator=g, requires_grad=True)
+    w, b = (0.5 + torch.rand(D, generator=g)).requires_grad_(), torch.randn(D, generator=g).requires_grad_()
+    y = F.layer_norm(x, (D,), w, b, eps=1e-5)
+    gy = torch.randn(rows, D, generator=g)
+    y.backward(gy)
+    xd, wd, bd = dev(x.detach()).requires_grad_(), dev(w.detach()).requires_grad_(), dev(b.detach()).requires_grad_()
+    z = ops.layernorm(xd, wd, bd)
+    z.backward(dev(gy))
+    close(z, y); close(xd.grad, x.grad, name="dx"); close(wd.grad, w.grad, name="dgamma"); close(bd.grad, b.grad, name="dbeta")
+
+
+def _ref_attn(qkv, H, win, mask, p):
+    B, T, _ = qkv.shape
+    d = qkv.shape[-1] // (3 * H)
+    t = qkv.reshape(B, T, 3, H, d).permute(2, 0, 3, 1, 4)
+    q, k, v = t[0], t[1], t[2]
+    qo, Sq, ko, Sk = win
+    a = ((q[:, :, qo:qo + Sq] @ k[:, :, ko:ko + Sk].transpose(-2, -1)) * d ** -0.5).softmax(-1)
+    if mask is not None:
+        a = a * mask.float() / (1 - p)
+    return (a @ v[:, :, ko:ko + Sk]).transpose(1, 2).reshape(B, Sq, H * d)
+
+
+@pytest.mark.parametrize("B,T,H,d,wins,use_mask", [
+    (3, 18, 8, 64, [(0, 18, 0, 18)], False), (2, 65, 8, 64, [(0, 65, 0, 65)], False),
+    (2, 12, 4, 128, [(1, 4, 1, 4), (5, 7, 5, 7), (0, 1, 0, 12)], True), (2, 114, 4, 128, [(1, 49, 1, 49), (50, 64, 50, 64), (0, 1, 0, 114)], True),
+    (2, 9, 4, 16, [(0, 9, 0, 9)], False)])
+def test_attention(ops, B, T, H, d, wins, use_mask):
+    g = torch.Generator().manual_seed(T)
+    qkv = torch.randn(B, T, 3 * H * d, generator=g, requires_grad=True)
+    masks = [(torch.rand(B, H, w[1], w[3], generator=g) >= 0.1) for w in wins] if use_mask else None
+    out = torch.zeros(B, T, H * d)
+    parts = []
+    for i, w in enumerate(wins):
+        parts.append((w, _ref_attn(qkv, H, w, masks[i] if masks else None, 0.1)))
+    out = torch.cat([p for _, p in sorted(parts, key=lambda x: x[0][0])], dim=1) if sum(w[1] for w in wins) == T else None
+    gy = torch.randn(B, T, H * d, generator=g)
+    loss = sum((p * gy[:, w[0]:w[0] + w[1]]).sum() for w, p in parts)
+    loss.backward()
+    qd = dev(qkv.detach()).requires_grad_()
+    md = [dev(m.to(torch.uint8)) for m in masks] if masks else None
+    o = ops.attention(qd, H, wins, md, 0.1 if masks else 0.0)
+    for w, p in parts:
+        close(o[:, w[0]:w[0] + w[1]], p, name=f"attn out {w}")
+    o.backward(dev(gy))
+    close(qd.grad, qkv.grad, tol=5e-5, name="dqkv")
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_linear_fn(ops, act):
+    g = torch.Generator().manual_seed(act)
+    x = torch.randn(6, 11, 48, generator=g, requires_grad=True)
+    w, b = torch.randn(70, 48, generator=g).requires_grad_(), torch.randn(70, generator=g).requires_grad_()
+    y = F.linear(x, w, b)
+    y = y if act == 0 else (F.relu(y) if act == 1 else F.gelu(y))
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd, wd, bd = dev(x.detach()).requires_grad_(), dev(w.detach()).requires_grad_(), dev(b.detach()).requires_grad_()
+    z = ops.linear(xd, wd, bd, act)
+    z.backward(dev(gy))
+    close(z, y); close(xd.grad, x.grad, name="dx"); close(wd.grad, w.grad, name="dw"); close(bd.grad, b.grad, name="db")
+
+
+@pytest.mark.parametrize("cat,ncon", [([3, 4, 5, 2, 6], 6), ([], 5), ([4, 4], 0)])
+def test_tab_embed(ops, cat, ncon):
+    from stil_tta_amd.modules import TabularTransformerEncoder
+    from types import SimpleNamespace
+    g = torch.Generator().manual_seed(len(cat))
+    B, D = 9, 64
+    enc = TabularTransformerEncoder(SimpleNamespace(tabular_embedding_dim=D, tabular_transformer_num_layers=0), cat, [1] * ncon)
+    cols = [torch.randint(0, c, (B, 1), generator=g).float() for c in cat] + [torch.randn(B, ncon, generator=g)]
+    x = torch.cat(cols, dim=1)
+    # CPU reference (models/Transformer.py:240-256)
+    parts = []
+    if cat:
+        parts.append(F.embedding(x[:, :len(cat)].long() + enc.cat_offsets.long(), enc.cat_embedding.weight))
+    if ncon:
+        parts.append(F.linear(x[:, len(cat):].unsqueeze(-1), enc.con_proj.weight, enc.con_proj.bias))
+    h = torch.cat([enc.cls_token.expand(B, -1, -1)] + parts, dim=1) + enc.column_embedding.weight.unsqueeze(0)
+    gy = torch.randn(h.shape, generator=g)
+    h.backward(gy)
+    ref = {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}
+    enc.zero_grad()
+    enc.cuda()
+    hd = ops.TabEmbedFn.apply(dev(x), enc.cat_embedding.weight if cat else None, enc.con_proj.weight if ncon else None,
+                              enc.con_proj.bias if ncon else None, enc.cls_token, enc.column_embedding.weight, enc.cat_offsets,
+                              enc.emb_rowcol, len(cat))
+    close(hd, h, name="embed")
+    hd.backward(dev(gy))
+    for n, p in enc.named_parameters():
+        if n in ref:
+            close(p.grad, ref[n], name="grad " + n)
+
+
+def test_small_losses(ops):
+    g = torch.Generator().manual_seed(0)
+    R, K, D = 13, 286, 128
+    z = (3 * torch.randn(R, K, generator=g)).requires_grad_()
+    y = torch.randint(0, K, (R,), generator=g)
+    q = torch.softmax(torch.randn(R, K, generator=g), 1)
+    w = (torch.rand(R, generator=g) > 0.4).float()
+    l1 = F.cross_entropy(z, y)
+    l2 = (F.cross_entropy(z, q, reduction="none") * w).mean()
+    (2 * l1 + 3 * l2).backward()
+    zd = dev(z.detach()).requires_grad_()
+    a = ops.CEHardFn.apply(zd, dev(y))
+    b = ops.CESoftFn.apply(zd, dev(q), dev(w))
+    (2 * a + 3 * b).backward()
+    close(a, l1, name="ce"); close(b, l2, name="soft ce"); close(zd.grad, z.grad, name="dlogits")
+    # normalize + token mean
+    x = torch.randn(R, 7, D, generator=g, requires_grad=True)
+    o = F.normalize(x.mean(1))
+    go = torch.randn(R, D, generator=g)
+    o.backward(go)
+    xd = dev(x.detach()).requires_grad_()
+    od = ops.l2norm(ops.tokmean(xd))
+    od.backward(dev(go))
+    close(od, o); close(xd.grad, x.grad, name="d normalize/mean")
+
+
+@pytest.mark.parametrize("B", [16, 100, 256])
+def test_clip_and_club(ops, B):
+    g = torch.Generator().manual_seed(B)
+    D = 128
+    f0, f1 = torch.randn(B, D, generator=g).requires_grad_(), torch.randn(B, D, generator=g).requires_grad_()
+    n0, n1 = F.normalize(f0), F.normalize(f1)
+    logits = n0 @ n1.t() / 0.1
+    lab = torch.arange(B)
+    ref = 0.3 * F.cross_entropy(logits, lab) + 0.7 * F.cross_entropy(logits.t(), lab)
+    ref.backward()
+    a, b = dev(f0.detach()).requires_grad_(), dev(f1.detach()).requires_grad_()
+    l, Z = ops.clip_loss(a, b, 0.1, 0.3)
+    l.backward()
+    close(l, ref, name="clip"); close(Z, logits, name="logits"); close(a.grad, f0.grad, name="df0"); close(b.grad, f1.grad, name="df1")
+    # CLUB: materialised [B,B,D] form of club.py:107-121 vs the closed form
+    mu, y = torch.randn(B, 64, generator=g).requires_grad_(), (0.5 + torch.randn(B, 64, generator=g)).requires_grad_()
+    pos = (-(mu - y) ** 2 / 2.0).sum(-1)
+    neg = (-((y.unsqueeze(0) - mu.unsqueeze(1)) ** 2).mean(dim=1) / 2.0).sum(-1)
+    club = (pos - neg).mean()
+    est = ((mu - y) ** 2).sum(1).mean(0)
+    (1.5 * club + 0.5 * est).backward()
+    md, yd = dev(mu.detach()).requires_grad_(), dev(y.detach()).requires_grad_()
+    c, e = ops.ClubFn.apply(md, yd)
+    (1.5 * c + 0.5 * e).backward()
+    close(c, club, name="club"); close(e, est, name="est"); close(md.grad, mu.grad, name="dmu"); close(yd.grad, y.grad, name="dy")
+
+
+def test_cgpl_pgls_and_prototypes(ops):
+    from stil_tta_amd._lib import lib
+    from stil_tta_amd.ops import _p, _stream
+    from oracle import stil_oracle as O
+    g = torch.Generator().manual_seed(1)
+    Bu, Bl, K, Dp = 40, 6, 11, 128
+    zm = torch.randn(Bu, K, generator=g)
+    zi = zm + 0.8 * torch.randn(Bu, K, generator=g)
+    zt = zm + 0.8 * torch.randn(Bu, K, generator=g)
+    feat = F.normalize(torch.randn(Bl + Bu, Dp, generator=g))
+    protos = F.normalize(torch.randn(K, Dp, generator=g))
+    mr = torch.rand(Bu, generator=g) >= 0.5
+    r, T, th = 0.9, 0.1, 0.45
+    a, b, d = zm.argmax(1), zi.argmax(1), zt.argmax(1)
+    c1 = (a == b) & (a == d); c2i = (a == b) & (a != d); c2t = (a == d) & (a != b); c3 = ~(c1 | c2i | c2t)
+    assert c1.any() and c2i.any() and c2t.any() and c3.any()
+    q0 = (c1[:, None] * ((zm + zi + zt) / 3.0).softmax(1) + c2i[:, None] * ((zm + zi) / 2.0).softmax(1)
+          + c2t[:, None] * ((zm + zt) / 2.0).softmax(1) + c3[:, None] * zm.softmax(1))
+    tp = torch.softmax(feat[Bl:] @ protos.t() / T, 1)
+    pl_ref = r * q0 + (1 - r) * tp
+    pred_ref = r * zm.softmax(1) + (1 - r) * tp
+    mask1 = pred_ref.max(1)[0].ge(th)
+    assert mask1.any() and (~mask1).any()
+    for use_pseudo in (True, False):
+        pl, po, pred, flags, hard, w3 = ops.cgpl_pgls(dev(zm), dev(zi), dev(zt), dev(feat[Bl:]), dev(protos), dev(mr.to(torch.uint8)), r, T, th,
+                                                      use_pseudo, want_orig=True)
+        close(pl, pl_ref, name="pseudo_label"); close(po, q0, name="pseudo_label_orig")
+        close(pred, pred_ref if use_pseudo else torch.zeros_like(pred_ref), name="prediction")
+        cs = flags[:, 0].cpu()
+        assert torch.equal(cs == 1, c1) and torch.equal(cs == 2, c2i) and torch.equal(cs == 3, c2t) and torch.equal(cs == 4, c3)
+        assert torch.equal(flags[:, 1].cpu().bool(), mask1)
+        close(w3[0], (mask1 & c1).float()); close(w3[1], (mask1 & (c1 | c2t | (c3 & mr))).float()); close(w3[2], (mask1 & (c1 | c2i | (c3 & ~mr))).float())
+        # prototype loss + accumulation against the oracle
+        y_l = torch.randint(0, K, (Bl,), generator=g)
+        label_all = torch.cat((F.one_hot(y_l, K).float(), pred_ref if use_pseudo else torch.zeros_like(pred_ref)))
+        fm = F.normalize(torch.randn(Bl + Bu, Dp, generator=g)).requires_grad_()
+        ref = O.prototype_loss(label_all, protos, fm, T, th)
+        ref.backward()
+        hard_all = torch.cat((dev(y_l).to(torch.int32), hard))
+        conf = torch.cat((torch.ones(Bl, dtype=torch.uint8, device="cuda"), flags[:, 2].contiguous()))
+        fd = dev(fm.detach()).requires_grad_()
+        l = ops.ProtoLossFn.apply(fd, dev(protos), hard_all, conf, T)
+        l.backward()
+        close(l, ref, name="proto loss"); close(fd.grad, fm.grad, name="proto dfeat")
+        ls, lc = O.cal_prototypes(label_all[:Bl], feat[:Bl], th)
+        us, uc = O.cal_prototypes(label_all[Bl:], feat[Bl:], th)
+        out = torch.empty(K, Dp + 1, device="cuda")
+        lib().proto_accum(_p(dev(feat)), _p(hard_all), _p(conf), _p(out), Bl + Bu, Bl, K, Dp, 2.0, _stream())
+        close(out[:, :Dp], ls / 2.0 + us, name="class_sum"); close(out[:, Dp:], lc / 2.0 + uc, name="class_count")
+
+
+def test_ema_and_adam_slabs():
+    from stil_tta_amd._lib import lib
+    from stil_tta_amd.ops import _p, _stream
+    from oracle import stil_oracle as O
+    g = torch.Generator().manual_seed(2)
+    n = 4096 * 3
+    e, v = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    ref = e.clone().mul_(0.996).add_((1.0 - 0.996) * v)
+    ed = dev(e)
+    lib().ema_update(_p(ed), _p(dev(v)), n, 0.996, _stream())
+    assert torch.equal(ed.cpu(), ref), "EMA must be bit-exact"
+    # Adam: 3 tensors of 1024-aligned slots, the middle one inactive (grad None in torch)
+    sd = {"a": torch.randn(1000, generator=g), "b": torch.randn(700, generator=g), "c": torch.randn(2048, generator=g)}
+    offs = {"a": 0, "b": 1024, "c": 2048}
+    total = 4096
+    P, G = torch.zeros(total), torch.zeros(total)
+    for k, t in sd.items():
+        P[offs[k]:offs[k] + t.numel()] = t
+    c2t = torch.tensor([0, 1, 2, 2], dtype=torch.int32)
+    Pd, Md, Vd = dev(P), torch.zeros(total, device="cuda"), torch.zeros(total, device="cuda")
+    steps = torch.zeros(3, dtype=torch.int32, device="cuda")
+    active = dev(torch.tensor([1, 0, 1], dtype=torch.uint8))
+    opt = {}
+    for step in (1, 2, 3):
+        grads = {"a": torch.randn(1000, generator=g), "c": torch.randn(2048, generator=g) * 1e-3}
+        G.zero_()
+        for k, t in grads.items():
+            G[offs[k]:offs[k] + t.numel()] = t
+        O.adam_step(sd, grads, opt, step, 1e-3, 0.01)
+        lib().adam_step(_p(Pd), _p(dev(G)), _p(Md), _p(Vd), _p(dev(c2t)), _p(steps), _p(active), 3, total, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1.0, _stream())
+    for k, t in sd.items():
+        close(Pd[offs[k]:offs[k] + t.numel()], t, tol=2e-6, name="adam " + k)
+    assert steps.cpu().tolist() == [3, 0, 3]
+
+
+def test_rng_mask_rate_and_determinism(ops):
+    a = ops.rng_mask((1 << 20,), 0.1, 7, 0, "cuda")
+    b = ops.rng_mask((1 << 20,), 0.1, 7, 0, "cuda")
+    c = ops.rng_mask((1 << 20,), 0.1, 7, 1 << 20, "cuda")
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert abs(float(a.float().mean()) - 0.9) < 2e-3

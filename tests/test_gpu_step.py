@@ -1,0 +1,219 @@
+"""GPU parity of the whole STiL training step (zero_grad -> training_step -> backward -> Adam) through the
+C ABI: (1) against the golden vectors recorded from the REAL reference (tests/golden/*.npz), (2) against the
+CPU oracle on the same seeded inputs at the reference-native DVM shape, (3) size-independent properties at the
+BASELINE.json bench shape.  Tolerance 1e-4 relative-to-scale (north_star: 1e-4 fp32)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-4
+
+
+def _close(a, b, tol=TOL):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = np.abs(b).max() if b.size else 0.0
+    err = np.abs(a - b)
+    return bool(np.all(err <= tol * (1.0 + np.abs(b) + scale))), float(err.max()) if err.size else 0.0
+
+
+def _make_model(hp, sd):
+    from stil_tta_amd import STiLModel
+    d = dict(vars(hp))
+    d["mi_dropout"] = False
+    m = STiLModel(d)
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict(sd)
+    m.setup_device("cuda")
+    m.train()
+    return m
+
+
+def _to_dev(batch):
+    out = {}
+    for k in ("l", "u"):
+        im, tab, y, orig, ident = batch[k]
+        out[k] = ([im[0].cuda(), im[1].cuda()], [tab[0].cuda(), tab[1].cuda()], y.cuda(), orig.cuda(), ident.cuda())
+    return out
+
+
+def _named_params(m):
+    return {n: p for n, p in m.named_parameters() if not n.startswith("ema.")}
+
+
+def _check_flags(last, o, B_u):
+    f = last["flags"].cpu()
+    cs = f[:, 0]
+    assert torch.equal(cs == 1, o["case1"]) and torch.equal(cs == 2, o["case2_i"])
+    assert torch.equal(cs == 3, o["case2_t"]) and torch.equal(cs == 4, o["case3"])
+    assert torch.equal(f[:, 1].bool(), o["mask1"])
+
+
+from oracle.make_golden import CASES, SCALARS, build_case  # noqa: E402
+from oracle import stil_oracle as O  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_training_step_matches_reference_golden(name):
+    from stil_tta_amd.driver import train_step
+    from stil_tta_amd.flat import StilAdam
+    fx = np.load(os.path.join(GOLD, name + ".npz"))
+    hp, sd, batch, epoch, mask_random, mi_masks = build_case(name)
+    m = _make_model(hp, sd)
+    m.current_epoch = epoch
+    opt = StilAdam(m.flat, lr=hp.lr_eval, weight_decay=hp.weight_decay_eval)
+    train_step(m, opt, _to_dev(batch), mask_random=mask_random, mi_masks=mi_masks)
+    torch.cuda.synchronize()
+    last = m.last
+    bad = []
+    for k in SCALARS:
+        ok, err = _close(last[k].detach().cpu().numpy(), fx["out_" + k])
+        if not ok:
+            bad.append((k, err))
+    for k in ["y_hat_m", "y_hat_i", "y_hat_t", "x_si_enhance", "x_si", "x_ai", "x_st_enhance", "x_st", "x_at", "x_c", "feat_m", "feat_i",
+              "feat_t", "y_hat_m_e", "y_hat_i_e", "y_hat_t_e", "feat_m_e", "pseudo_label_orig", "pseudo_label", "prediction",
+              "class_sum", "class_count"]:
+        ok, err = _close(last[k].detach().cpu().numpy(), fx["out_" + k])
+        if not ok:
+            bad.append((k, err))
+    f = last["flags"].cpu().numpy()
+    for cid, key in ((1, "case1"), (2, "case2_i"), (3, "case2_t"), (4, "case3")):
+        assert np.array_equal(f[:, 0] == cid, fx["out_" + key]), key
+    assert np.array_equal(f[:, 1].astype(bool), fx["out_mask1"])
+    params = _named_params(m)
+    for key in fx.files:
+        if key.startswith("gnorm_"):
+            p = params[key[6:]]
+            n = float(p._gslot.double().norm()) if p._stil_touched else 0.0
+            ref = float(fx[key])
+            if abs(n - ref) > 2e-4 * (1e-6 + ref) + 1e-6:
+                bad.append((key, n, ref))
+        elif key.startswith("grad_"):
+            ok, err = _close(params[key[5:]]._gslot.cpu().numpy(), fx[key], 2e-4)
+            if not ok:
+                bad.append((key, err))
+        elif key.startswith("ssum_"):
+            v = m.state_dict()[key[5:]].double()
+            ref_abs = float(fx["sabs_" + key[5:]])
+            if abs(float(v.sum()) - float(fx[key])) > 5e-5 * (1.0 + ref_abs):
+                bad.append((key, float(v.sum()), float(fx[key])))
+    assert not bad, f"{len(bad)} mismatches, first: {bad[:10]}"
+
+
+def test_two_steps_match_oracle_dvm_native_shape():
+    """DVM-native config (128 px, 4 cat + 13 con, K = 286), B = 16, two consecutive steps incl. Adam + EMA +
+    BN running stats + prototype commit, against the CPU oracle on identical seeded inputs."""
+    from stil_tta_amd.driver import train_step
+    from stil_tta_amd.flat import StilAdam
+    from oracle.make_golden import randomize_state, make_mi_masks
+    hp = O.default_hparams(batch_size=16, start_epoch=0, th1=0.02)
+    sd = randomize_state(O.init_state(hp, seed=3), seed=4)
+    g = torch.Generator().manual_seed(7)
+    sd["prototypes"] = torch.nn.functional.normalize(torch.randn(hp.num_classes, hp.projection_dim, generator=g))
+    m = _make_model(hp, {k: v.clone() for k, v in sd.items()})
+    m.current_epoch = 1
+    opt = StilAdam(m.flat, lr=hp.lr_eval)
+    oopt = {}
+    for step in (1, 2):
+        batch = O.synthetic_batch(hp, 16, seed=100 + step)
+        mr = torch.rand(14, generator=g).ge(0.5)
+        mm = {0: make_mi_masks(16, 16, 17, 512, 4, 0.1, seed=step)}
+        o = O.full_step(sd, oopt, step, batch, hp, 1, mr, mm)
+        train_step(m, opt, _to_dev(batch), mask_random=mr, mi_masks=mm)
+        torch.cuda.synchronize()
+        bad = []
+        for k in SCALARS + ["y_hat_m", "y_hat_m_e", "feat_m", "feat_m_e", "pseudo_label", "prediction", "class_sum", "class_count"]:
+            ok, err = _close(m.last[k].detach().cpu().numpy(), o[k].numpy())
+            if not ok:
+                bad.append((step, k, err))
+        _check_flags(m.last, o, 14)
+        params = _named_params(m)
+        for k, gr in o["grads"].items():
+            if gr is None:
+                assert not params[k]._stil_touched, k
+                continue
+            ok, err = _close(params[k]._gslot.cpu().numpy(), gr.numpy(), 2e-4)
+            if not ok:
+                bad.append((step, "grad " + k, err))
+        msd = m.state_dict()
+        tr = set(O.trainable_keys(sd))
+        for k, v in sd.items():
+            if k in tr:
+                if float((msd[k].cpu() - v).abs().max()) > 2.2 * hp.lr_eval * step:
+                    bad.append((step, "adam " + k))
+            else:
+                ok, err = _close(msd[k].cpu().double().numpy(), v.double().numpy(), 5e-5)
+                if not ok:
+                    bad.append((step, "state " + k, err))
+        assert not bad, f"{len(bad)} mismatches, first: {bad[:10]}"
+        # keep both sides on identical parameters so step 2 tests the step, not Adam's noise amplification
+        m.load_state_dict({k: v.clone() for k, v in sd.items()})
+    O.training_epoch_end(sd) if bool((sd["prototypes_count_sum"] >= 1).all()) else None
+
+
+def test_bench_shape_properties():
+    """BASELINE configs[1] shape (224 px, 64 columns, K = 286) at B = 32: size-independent properties."""
+    from stil_tta_amd import STiLModel
+    from stil_tta_amd.driver import train_step, synthetic_batch
+    from stil_tta_amd.flat import StilAdam
+    torch.manual_seed(0)
+    fl = [8] * 16 + [1] * 48
+    m = STiLModel(dict(field_lengths=fl, num_classes=286, start_epoch=0, batch_size=32, th1=0.0))
+    m.setup_device("cuda")
+    m.train()
+    m.current_epoch = 1
+    m.prototypes.copy_(torch.nn.functional.normalize(torch.randn(286, 128, device="cuda")))
+    opt = StilAdam(m.flat, lr=1e-4)
+    batch = synthetic_batch(fl, 286, 32, 224, device="cuda")
+    ema0 = m.flat.ema.clone()
+    p0 = m.flat.params.clone()
+    loss = train_step(m, opt, batch)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(loss))
+    L = m.last
+    for k in ("feat_m", "feat_i", "feat_t", "feat_m_e"):  # unit rows
+        assert float((L[k].norm(dim=1) - 1).abs().max()) < 1e-5, k
+    for k in ("pseudo_label", "pseudo_label_orig", "prediction"):  # rows are distributions
+        assert float((L[k].sum(1) - 1).abs().max()) < 1e-5, k
+    f = L["flags"].cpu()
+    assert int(((f[:, 0] >= 1) & (f[:, 0] <= 4)).sum()) == 28  # the four cases partition the unlabelled rows
+    # th1 = 0: every row is confident -> counts sum to the batch; class sums add up to the feature sum
+    assert abs(float(L["class_count"].sum()) - 32.0) < 1e-4
+    assert float((L["class_sum"].sum(0) - L["feat_m_e"].sum(0)).abs().max()) < 1e-4
+    # EMA: e' = m e + (1-m) p (student BEFORE Adam), exact
+    n = m.flat.n_backbone_params
+    ref = ema0[:n].mul(0.996).add((1.0 - 0.996) * p0[:n])
+    assert torch.equal(m.flat.ema[:n], ref)
+    # Adam moved every touched parameter by at most lr (first step: |m/sqrt(v)| <= 1)
+    d = (m.flat.params - p0).abs()
+    assert float(d[: n].max()) <= 1.0001e-4 and float(d.max()) > 0
+    # total loss is the weighted sum of its logged parts (STiLModel.py:345)
+    hp = m.hp
+    tot = hp.alpha * L["loss_ce"] + hp.beta * L["loss_itc"] + hp.gamma * (L["loss_club_i"] + L["loss_club_i_est"] + L["loss_club_t"] + L["loss_club_t_est"]) \
+        + hp.rate_pt * L["loss_pt"] + hp.rate_uce * (L["loss_m_u"] + L["loss_i_u"] + L["loss_t_u"])
+    assert abs(float(tot) - float(L["loss"])) < 1e-4 * (1 + abs(float(tot)))
+    # determinism: an identical second model/step gives bit-identical loss and gradients
+    g1 = m.flat.grads.clone()
+    torch.manual_seed(0)
+    m2 = STiLModel(dict(field_lengths=fl, num_classes=286, start_epoch=0, batch_size=32, th1=0.0))
+    m2.setup_device("cuda"); m2.train(); m2.current_epoch = 1
+    m2.flat.params.copy_(p0); m2.flat.copy_student_to_teacher(); m2.flat.ema.copy_(ema0)
+    m2.prototypes.copy_(m.prototypes)
+    loss2 = train_step(m2, StilAdam(m2.flat, lr=1e-4), batch)
+    assert torch.equal(loss, loss2) and torch.equal(g1, m2.flat.grads)
+
+
+def test_empty_and_ragged_inputs_fail_loudly():
+    from stil_tta_amd import ops
+    x = torch.randn(4, 8)
+    with pytest.raises(RuntimeError):  # CPU tensors are refused: no fallback
+        ops.linear(x, torch.randn(3, 8), None)
+    with pytest.raises(RuntimeError):  # non-contiguous
+        ops.L2NormFn.apply(torch.randn(8, 4, device="cuda").t())
+    with pytest.raises(RuntimeError):  # conv with Cin not a multiple of 16
+        ops.gemm_nt(torch.randn(9, 3, device="cuda"), torch.randn(4, 27, device="cuda"), 9, 4, 27, geom=(3, 3, 3, 3, 3, 3, 3, 1, 1, 0))
