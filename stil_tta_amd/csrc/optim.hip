@@ -11,13 +11,15 @@
 // e = m*e + (1-m)*v with the reference's rounding: fl(fl(m*e) + fl(c*v)), c = float(1-m)
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ e, const float* __restrict__ v, long n4, float m,
                                                    float c) {
+#pragma clang fp contract(off)  // HIP's __fmul_rn/__fadd_rn are plain operators: forbid FMA contraction here
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     float4 a = reinterpret_cast<float4*>(e)[i];
     const float4 b = reinterpret_cast<const float4*>(v)[i];
-    a.x = __fadd_rn(__fmul_rn(a.x, m), __fmul_rn(c, b.x));
-    a.y = __fadd_rn(__fmul_rn(a.y, m), __fmul_rn(c, b.y));
-    a.z = __fadd_rn(__fmul_rn(a.z, m), __fmul_rn(c, b.z));
-    a.w = __fadd_rn(__fmul_rn(a.w, m), __fmul_rn(c, b.w));
+    float t0, t1;
+    t0 = a.x * m; t1 = c * b.x; a.x = t0 + t1;
+    t0 = a.y * m; t1 = c * b.y; a.y = t0 + t1;
+    t0 = a.z * m; t1 = c * b.z; a.z = t0 + t1;
+    t0 = a.w * m; t1 = c * b.w; a.w = t0 + t1;
     reinterpret_cast<float4*>(e)[i] = a;
   }
 }

@@ -258,7 +258,7 @@ class ConvBnActFn(torch.autograd.Function):
             gamma._stil_touched = True
             beta._stil_touched = True
         if has_res:
-            dres = (gres if relu else gz).view(Nb, OH, OW, Cout)
+            dres = gres if relu else gz.view(M, Cout)
         else:
             dres = None
         dx = None

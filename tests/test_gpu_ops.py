@@ -380,8 +380,8 @@ def test_ema_and_adam_slabs():
     n = 4096 * 3
     e, v = torch.randn(n, generator=g), torch.randn(n, generator=g)
     ref = e.clone().mul_(0.996).add_((1.0 - 0.996) * v)
-    ed = dev(e)
-    lib().ema_update(_p(ed), _p(dev(v)), n, 0.996, _stream())
+    ed, vd = dev(e), dev(v)
+    lib().ema_update(_p(ed), _p(vd), n, 0.996, _stream())
     assert torch.equal(ed.cpu(), ref), "EMA must be bit-exact"
     # Adam: 3 tensors of 1024-aligned slots, the middle one inactive (grad None in torch)
     sd = {"a": torch.randn(1000, generator=g), "b": torch.randn(700, generator=g), "c": torch.randn(2048, generator=g)}
@@ -401,7 +401,8 @@ def test_ema_and_adam_slabs():
         for k, t in grads.items():
             G[offs[k]:offs[k] + t.numel()] = t
         O.adam_step(sd, grads, opt, step, 1e-3, 0.01)
-        lib().adam_step(_p(Pd), _p(dev(G)), _p(Md), _p(Vd), _p(dev(c2t)), _p(steps), _p(active), 3, total, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1.0, _stream())
+        Gd, c2td = dev(G), dev(c2t)  # keep the device buffers alive until the launch is enqueued
+        lib().adam_step(_p(Pd), _p(Gd), _p(Md), _p(Vd), _p(c2td), _p(steps), _p(active), 3, total, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1.0, _stream())
     for k, t in sd.items():
         close(Pd[offs[k]:offs[k] + t.numel()], t, tol=2e-6, name="adam " + k)
     assert steps.cpu().tolist() == [3, 0, 3]

@@ -86,17 +86,25 @@ def test_training_step_matches_reference_golden(name):
         assert np.array_equal(f[:, 0] == cid, fx["out_" + key]), key
     assert np.array_equal(f[:, 1].astype(bool), fx["out_mask1"])
     params = _named_params(m)
+    # Gradients: deep train-mode-BN backward amplifies fp32 rounding, so the yardstick is the float64 truth.  The
+    # fixture stores gerr32 = relL2(reference fp32 grad, fp64 grad); the HIP path must be as close to fp64 as the
+    # reference's own CPU fp32 path: <= 3 * gerr32 + 2e-5 (full tensors) / the same bound on norms.
     for key in fx.files:
         if key.startswith("gnorm_"):
             p = params[key[6:]]
             n = float(p._gslot.double().norm()) if p._stil_touched else 0.0
-            ref = float(fx[key])
-            if abs(n - ref) > 2e-4 * (1e-6 + ref) + 1e-6:
-                bad.append((key, n, ref))
-        elif key.startswith("grad_"):
-            ok, err = _close(params[key[5:]]._gslot.cpu().numpy(), fx[key], 2e-4)
-            if not ok:
-                bad.append((key, err))
+            if "g64norm_" + key[6:] not in fx.files:
+                assert n == 0.0, key  # grad None in the reference
+                continue
+            n64, e32 = float(fx["g64norm_" + key[6:]]), float(fx["gerr32_" + key[6:]])
+            if abs(n - n64) > (3 * e32 + 2e-5) * n64 + 1e-9:
+                bad.append((key, n, n64, e32))
+        elif key.startswith("grad64_"):
+            g64 = fx[key].astype(np.float64)
+            e32 = float(fx["gerr32_" + key[7:]])
+            err = np.linalg.norm(params[key[7:]]._gslot.cpu().double().numpy() - g64) / (np.linalg.norm(g64) + 1e-30)
+            if err > 3 * e32 + 2e-5:
+                bad.append((key, err, e32))
         elif key.startswith("ssum_"):
             v = m.state_dict()[key[5:]].double()
             ref_abs = float(fx["sabs_" + key[5:]])
@@ -110,7 +118,7 @@ def test_two_steps_match_oracle_dvm_native_shape():
     BN running stats + prototype commit, against the CPU oracle on identical seeded inputs."""
     from stil_tta_amd.driver import train_step
     from stil_tta_amd.flat import StilAdam
-    from oracle.make_golden import randomize_state, make_mi_masks
+    from oracle.make_golden import randomize_state, make_mi_masks, run_oracle64
     hp = O.default_hparams(batch_size=16, start_epoch=0, th1=0.02)
     sd = randomize_state(O.init_state(hp, seed=3), seed=4)
     g = torch.Generator().manual_seed(7)
@@ -123,7 +131,9 @@ def test_two_steps_match_oracle_dvm_native_shape():
         batch = O.synthetic_batch(hp, 16, seed=100 + step)
         mr = torch.rand(14, generator=g).ge(0.5)
         mm = {0: make_mi_masks(16, 16, 17, 512, 4, 0.1, seed=step)}
+        sd_before = {k: v.clone() for k, v in sd.items()}
         o = O.full_step(sd, oopt, step, batch, hp, 1, mr, mm)
+        o64 = run_oracle64(hp, sd_before, batch, 1, mr, mm)  # float64 truth for the gradients
         train_step(m, opt, _to_dev(batch), mask_random=mr, mi_masks=mm)
         torch.cuda.synchronize()
         bad = []
@@ -133,13 +143,18 @@ def test_two_steps_match_oracle_dvm_native_shape():
                 bad.append((step, k, err))
         _check_flags(m.last, o, 14)
         params = _named_params(m)
+        worst = 0.0
         for k, gr in o["grads"].items():
             if gr is None:
                 assert not params[k]._stil_touched, k
                 continue
-            ok, err = _close(params[k]._gslot.cpu().numpy(), gr.numpy(), 2e-4)
-            if not ok:
-                bad.append((step, "grad " + k, err))
+            g64 = o64["grads"][k]
+            e32 = float((gr.double() - g64).norm() / (g64.norm() + 1e-30))
+            eg = float((params[k]._gslot.cpu().double() - g64).norm() / (g64.norm() + 1e-30))
+            worst = max(worst, eg / (3 * e32 + 2e-5))
+            if eg > 3 * e32 + 2e-5:
+                bad.append((step, "grad " + k, eg, e32))
+        print(f"step {step}: worst gradient error ratio vs bound {worst:.3f}")
         msd = m.state_dict()
         tr = set(O.trainable_keys(sd))
         for k, v in sd.items():
@@ -191,7 +206,7 @@ def test_bench_shape_properties():
     assert torch.equal(m.flat.ema[:n], ref)
     # Adam moved every touched parameter by at most lr (first step: |m/sqrt(v)| <= 1)
     d = (m.flat.params - p0).abs()
-    assert float(d[: n].max()) <= 1.0001e-4 and float(d.max()) > 0
+    assert float(d[: n].max()) <= 1.001e-4 and float(d.max()) > 0
     # total loss is the weighted sum of its logged parts (STiLModel.py:345)
     hp = m.hp
     tot = hp.alpha * L["loss_ce"] + hp.beta * L["loss_itc"] + hp.gamma * (L["loss_club_i"] + L["loss_club_i_est"] + L["loss_club_t"] + L["loss_club_t_est"]) \
