@@ -29,7 +29,7 @@ int stil_version(void);
 int stil_device_count(void);
 
 /* ---- GEMM / convolution (fp32-exact MFMA, v_mfma_f32_32x32x2_f32) -------------------------
- * C[M,N] = act( (alpha * Agather[M,K] . W[N,K]^T) * scale[n] + shift[n] + bias[n] + resid[m,n] )
+ * C[M,N] = act( (alpha * Agather[M,K] . W[N,K]^T - sub[n]) * scale[n] + shift[n] + bias[n] + resid[m,n] )
  * Agather row m = (n, oy, ox) over an NHWC source [*, srcH, srcW, srcC] (row stride lda),
  * k = (ky*KW + kx)*srcC + c.  mode 0: iy = oy*stride - pad + ky (forward);  mode 1: iy = (oy + pad - ky)/stride
  * when divisible (input-gradient of a strided conv).  A plain GEMM is srcH=srcW=OH=OW=KH=KW=1, srcC=K.
@@ -38,8 +38,8 @@ int stil_device_count(void);
  * models/Transformer.py:27-33,63-88, STiLModel_backbone.py:19-32,139,153-155. */
 int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                  int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad, int mode,
-                 const float* bias, const float* scale, const float* shift, const float* resid, int ldr,
-                 float* pre, int act, float alpha, void* stream);
+                 const float* bias, const float* sub, const float* scale, const float* shift, const float* resid,
+                 int ldr, float* pre, int act, float alpha, void* stream);
 
 /* tile variant stil_gemm_nt launches for an [M,N] output: 22 = 128x128, 21 = 128x64, 11 = 64x64 (bench bookkeeping) */
 int stil_gemm_nt_variant(int M, int N);
@@ -64,7 +64,7 @@ int stil_im2col_nchw(const float* x, float* col, int N, int Cin, int H, int W, i
 int stil_transpose(const float* in, float* out, int R, int C, void* stream);
 
 /* ---- BatchNorm2d (NHWC rows), ReLU, residual, max-pool: models/resnets.py:112-132,248-252 ----
- * stats: [4,C] = mean, rstd, a=gamma*rstd, b=beta-mean*a.  Train forward also updates the running
+ * stats: [4,C] = mean, rstd, a=gamma*rstd, beta (z = (x-mean)*a + beta); bn_eval_affine's ab: [3,C] = a, beta, running_mean.  Train forward also updates the running
  * statistics (momentum, unbiased variance) and num_batches_tracked. z = relu?(x*a + b + resid). */
 size_t stil_bn_workspace_bytes(int M, int C);
 int stil_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,

@@ -11,15 +11,29 @@ static inline int pick_ctile(int C) {
   return 0;
 }
 
-// ---- statistics: shifted one-pass sums  S1 = sum(x - K), S2 = sum((x - K)^2),  K = x[0, c]
-__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, float* __restrict__ part,
+// ---- statistics: shifted one-pass sums  S1 = sum(x - K), S2 = sum((x - K)^2).
+// The shift K[c] is a PILOT MEAN over <= 256 rows spread across the tensor (bn_pilot_kernel): |K - mean| << std, so
+// var = S2/M - (S1/M)^2 has no cancellation (a single sample such as x[0,c] -- a zero-padded corner pixel -- is up
+// to several sigma off and cost ~3x the forward error of ATen's two-pass variance).
+__global__ void bn_pilot_kernel(const float* __restrict__ x, float* __restrict__ K, int M, int C) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  int n = M < 256 ? M : 256;
+  long stride = M / n;
+  float s = 0.f;
+  for (int j = 0; j < n; ++j) s += x[(long)j * stride * C + c];
+  K[c] = s / (float)n;
+}
+
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, const float* __restrict__ Kp,
+                                                                float* __restrict__ part,
                                                                 int M, int C, int ctile, int rows_per_chunk) {
   __shared__ float sh[2 * 1024];
   const int tpr = ctile >> 2, rpb = 256 / tpr;
   const int tc = threadIdx.x % tpr, rl = threadIdx.x / tpr;
   const int c = blockIdx.x * ctile + tc * 4;
   const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
-  const float4 K = *reinterpret_cast<const float4*>(x + c);
+  const float4 K = *reinterpret_cast<const float4*>(Kp + c);
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
   for (int m = m0 + rl; m < m1; m += rpb) {
     float4 v = *reinterpret_cast<const float4*>(x + (long)m * C + c);
@@ -44,8 +58,8 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
   }
 }
 
-// stats[0]=mean, [1]=rstd, [2]=a=gamma*rstd, [3]=b=beta-mean*a ; updates running stats (momentum, unbiased var)
-__global__ void bn_stats_final_kernel(const float* __restrict__ x, const float* __restrict__ part, int nch, int M, int C,
+// stats[0]=mean, [1]=rstd, [2]=a=gamma*rstd, [3]=beta ; updates running stats (momentum, unbiased var)
+__global__ void bn_stats_final_kernel(const float* __restrict__ Kp, const float* __restrict__ part, int nch, int M, int C,
                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                       float* __restrict__ rmean, float* __restrict__ rvar, long long* nbt,
                                       float* __restrict__ stats, float eps, float momentum) {
@@ -56,12 +70,12 @@ __global__ void bn_stats_final_kernel(const float* __restrict__ x, const float* 
   for (int i = 0; i < nch; ++i) { s1 += part[(long)i * C + c]; s2 += part[(long)(nch + i) * C + c]; }
   const float invM = 1.f / (float)M;
   const float d = s1 * invM;
-  const float mean = x[c] + d;
+  const float mean = Kp[c] + d;
   float var = s2 * invM - d * d;
   var = fmaxf(var, 0.f);
   const float rstd = 1.f / sqrtf(var + eps);
   const float a = gamma[c] * rstd;
-  stats[c] = mean; stats[C + c] = rstd; stats[2 * C + c] = a; stats[3 * C + c] = beta[c] - mean * a;
+  stats[c] = mean; stats[C + c] = rstd; stats[2 * C + c] = a; stats[3 * C + c] = beta[c];
   if (rmean) {
     rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
     float unb = (M > 1) ? var * ((float)M / (float)(M - 1)) : var;
@@ -69,17 +83,18 @@ __global__ void bn_stats_final_kernel(const float* __restrict__ x, const float* 
   }
 }
 
-// eval mode: a = gamma / sqrt(running_var + eps), b = beta - running_mean * a   (folded into the conv epilogue)
+// eval mode: ab[0] = a = gamma / sqrt(running_var + eps), ab[1] = beta, ab[2] = running_mean.  The conv epilogue
+// applies (y - mean) * a + beta: the subtractive form keeps ATen's accuracy (no x*a - mean*a cancellation).
 __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                       const float* __restrict__ rmean, const float* __restrict__ rvar,
                                       float* __restrict__ ab, int C, float eps) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float a = gamma[c] / sqrtf(rvar[c] + eps);
-  ab[c] = a; ab[C + c] = beta[c] - rmean[c] * a;
+  ab[c] = a; ab[C + c] = beta[c]; ab[2 * C + c] = rmean[c];
 }
 
-// z = relu?( x*a + b (+ resid) )
+// z = relu?( (x - mean)*a + beta (+ resid) )
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                         const float* __restrict__ resid, float* __restrict__ z,
                                                         long total4, int C, int relu) {
@@ -90,7 +105,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     float4 v = reinterpret_cast<const float4*>(x)[i];
     const float4 a = *reinterpret_cast<const float4*>(A + c);
     const float4 b = *reinterpret_cast<const float4*>(B + c);
-    v.x = v.x * a.x + b.x; v.y = v.y * a.y + b.y; v.z = v.z * a.z + b.z; v.w = v.w * a.w + b.w;
+    const float4 mu = *reinterpret_cast<const float4*>(stats + c);
+    v.x = (v.x - mu.x) * a.x + b.x; v.y = (v.y - mu.y) * a.y + b.y; v.z = (v.z - mu.z) * a.z + b.z; v.w = (v.w - mu.w) * a.w + b.w;
     if (resid) {
       const float4 r = reinterpret_cast<const float4*>(resid)[i];
       v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
@@ -276,7 +292,7 @@ static inline int bn_chunks(int M, int C, int ctile) {
 extern "C" size_t stil_bn_workspace_bytes(int M, int C) {
   int ct = pick_ctile(C);
   if (!ct) return 0;
-  return (size_t)2 * bn_chunks(M, C, ct) * C * sizeof(float);
+  return ((size_t)2 * bn_chunks(M, C, ct) + 1) * C * sizeof(float);
 }
 
 extern "C" int stil_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
@@ -287,12 +303,15 @@ extern "C" int stil_bn_train_fwd(const float* x, const float* gamma, const float
   int ct = pick_ctile(C);
   STIL_REQUIRE(ct != 0, "stil_bn_train_fwd: C=%d must be a multiple of 64", C);
   int nch = bn_chunks(M, C, ct);
-  STIL_REQUIRE(workspace_bytes >= (size_t)2 * nch * C * sizeof(float), "stil_bn_train_fwd: workspace too small");
+  STIL_REQUIRE(workspace_bytes >= ((size_t)2 * nch + 1) * C * sizeof(float), "stil_bn_train_fwd: workspace too small");
+  float* pilot = workspace + (size_t)2 * nch * C;
   int rpc = cdiv(M, nch);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C / ct, nch), dim3(256), 0, s, x, workspace, M, C, ct, rpc);
+  hipLaunchKernelGGL(bn_pilot_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, x, pilot, M, C);
   STIL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, x, workspace, nch, M, C, gamma, beta,
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C / ct, nch), dim3(256), 0, s, x, pilot, workspace, M, C, ct, rpc);
+  STIL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, pilot, workspace, nch, M, C, gamma, beta,
                      running_mean, running_var, num_batches_tracked, stats, eps, momentum);
   STIL_LAUNCH_CHECK();
   long total4 = (long)M * C / 4;

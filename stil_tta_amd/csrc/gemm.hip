@@ -32,6 +32,7 @@ struct GemmNTArgs {
   int lda, ldb, ldc;
   ConvGeom g;
   const float* bias;
+  const float* sub;    // per-column subtrahend (eval BatchNorm running mean)
   const float* scale;
   const float* shift;
   const float* resid;
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
     const int col = tn * BN + wn * TN * 32 + j * 32 + li;
     if (col >= p.N) continue;
     const float bia = p.bias ? p.bias[col] : 0.f;
+    const float sb = p.sub ? p.sub[col] : 0.f;
     const float sc = p.scale ? p.scale[col] : 1.f;
     const float sh = p.shift ? p.shift[col] : 0.f;
 #pragma unroll
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
         const int row = tm * BM + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row >= p.M) continue;
         float v = acc[i][j][r] * p.alpha;
-        v = v * sc + sh + bia;
+        v = (v - sb) * sc + sh + bia;
         if (p.resid) v += p.resid[(long)row * p.ldr + col];
         if (p.pre) p.pre[(long)row * p.ldc + col] = v;
         if (p.act == 1) v = fmaxf(v, 0.f);
@@ -380,15 +382,16 @@ extern "C" int stil_gemm_nt_variant(int M, int N) {
 
 extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                             int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad,
-                            int mode, const float* bias, const float* scale, const float* shift,
-                            const float* resid, int ldr, float* pre, int act, float alpha, void* stream) {
+                            int mode, const float* bias, const float* sub, const float* scale,
+                            const float* shift, const float* resid, int ldr, float* pre, int act, float alpha,
+                            void* stream) {
   STIL_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0, "stil_gemm_nt: null pointer or empty shape (M=%d N=%d K=%d)", M, N, K);
   STIL_REQUIRE(KH * KW * srcC == K, "stil_gemm_nt: K=%d != KH*KW*C=%d", K, KH * KW * srcC);
   STIL_REQUIRE(M % (OH * OW) == 0, "stil_gemm_nt: M=%d not a multiple of OH*OW=%d", M, OH * OW);
   GemmNTArgs p;
   p.A = A; p.Bw = W; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.g = ConvGeom{srcH, srcW, srcC, OH, OW, KH, KW, stride, pad, mode};
-  p.bias = bias; p.scale = scale; p.shift = shift; p.resid = resid; p.ldr = ldr; p.pre = pre; p.act = act;
+  p.bias = bias; p.sub = sub; p.scale = scale; p.shift = shift; p.resid = resid; p.ldr = ldr; p.pre = pre; p.act = act;
   p.alpha = alpha;
   p.vecA = is_vec(A, lda) && (srcC % 4 == 0);
   p.vecB = is_vec(W, ldb);

@@ -67,7 +67,7 @@ def _grad_into(param: torch.Tensor, writer):
 
 
 # ------------------------------------------------------------------------------------------ raw wrappers
-def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None, bias=None, scale=None, shift=None,
+def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None, bias=None, sub=None, scale=None, shift=None,
             resid=None, pre=None, act=0, alpha=1.0):
     """C = epilogue(alpha * Agather . W^T).  geom = (srcH, srcW, srcC, OH, OW, KH, KW, stride, pad, mode)."""
     if geom is None:
@@ -82,7 +82,7 @@ def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None,
     if L._prof is not None:  # bench bookkeeping: tile variant + ALGORITHMIC flops (strided dgrad gathers count the conv's flops)
         s2 = geom[7] * geom[7] if geom[9] == 1 else 1
         meta = (L.gemm_nt_variant(M, N), 2.0 * M * N * K / s2)
-    L.gemm_nt(_p(A), _p(W), _p(out), M, N, K, lda, ldb, ldc, *geom, _p(bias), _p(scale), _p(shift), _p(resid),
+    L.gemm_nt(_p(A), _p(W), _p(out), M, N, K, lda, ldb, ldc, *geom, _p(bias), _p(sub), _p(scale), _p(shift), _p(resid),
               (ldc if resid is not None else 0), _p(pre), act, float(alpha), _stream(), meta=meta)
     return out
 
@@ -287,12 +287,12 @@ def conv_bn_eval(x, w, gamma, beta, rmean, rvar, resid, k, stride, pad, relu, st
     """Teacher path: eval-mode BN folded into the conv epilogue (no grad)."""
     Cout = w.shape[0]
     dev = x.device
-    ab = torch.empty((2, Cout), dtype=torch.float32, device=dev)
+    ab = torch.empty((3, Cout), dtype=torch.float32, device=dev)
     lib().bn_eval_affine(_p(gamma), _p(beta), _p(rmean), _p(rvar), _p(ab), Cout, 1e-5, _stream())
     if stem is not None:
         Nb, OH, OW, Kp, wpad = stem
         M = Nb * OH * OW
-        z = gemm_nt(x, wpad, M, Cout, Kp, scale=ab[0], shift=ab[1], resid=resid, act=1 if relu else 0)
+        z = gemm_nt(x, wpad, M, Cout, Kp, sub=ab[2], scale=ab[0], shift=ab[1], resid=resid, act=1 if relu else 0)
         return z.view(Nb, OH, OW, Cout)
     Nb, H, W_, Cin = x.shape
     OH = (H + 2 * pad - k) // stride + 1
@@ -303,7 +303,7 @@ def conv_bn_eval(x, w, gamma, beta, rmean, rvar, resid, k, stride, pad, relu, st
     else:
         wf = torch.empty((Cout, k * k * Cin), dtype=torch.float32, device=dev)
         lib().conv_weight_layout(_p(w), _p(wf), None, Cout, Cin, k, k, _stream())
-    z = gemm_nt(x, wf, M, Cout, k * k * Cin, geom=_conv_geom_fwd(H, W_, Cin, OH, OW, k, stride, pad), scale=ab[0],
+    z = gemm_nt(x, wf, M, Cout, k * k * Cin, geom=_conv_geom_fwd(H, W_, Cin, OH, OW, k, stride, pad), sub=ab[2], scale=ab[0],
                 shift=ab[1], resid=resid, act=1 if relu else 0)
     return z.view(Nb, OH, OW, Cout)
 

