@@ -15,14 +15,22 @@ static inline int pick_ctile(int C) {
 // The shift K[c] is a PILOT MEAN over <= 256 rows spread across the tensor (bn_pilot_kernel): |K - mean| << std, so
 // var = S2/M - (S1/M)^2 has no cancellation (a single sample such as x[0,c] -- a zero-padded corner pixel -- is up
 // to several sigma off and cost ~3x the forward error of ATen's two-pass variance).
-__global__ void bn_pilot_kernel(const float* __restrict__ x, float* __restrict__ K, int M, int C) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  int n = M < 256 ? M : 256;
-  long stride = M / n;
+__global__ __launch_bounds__(256) void bn_pilot_kernel(const float* __restrict__ x, float* __restrict__ K, int M, int C) {
+  __shared__ float sh[8 * 32];
+  const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;  // 32 channels x 8 row lanes
+  const int c = blockIdx.x * 32 + cl;
+  const int n = M < 256 ? M : 256;
+  const long stride = M / n;
   float s = 0.f;
-  for (int j = 0; j < n; ++j) s += x[(long)j * stride * C + c];
-  K[c] = s / (float)n;
+  if (c < C)
+    for (int j = lane; j < n; j += 8) s += x[(long)j * stride * C + c];
+  sh[lane * 32 + cl] = s;
+  __syncthreads();
+  if (lane == 0 && c < C) {
+    float t = 0.f;
+    for (int l = 0; l < 8; ++l) t += sh[l * 32 + cl];
+    K[c] = t / (float)n;
+  }
 }
 
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, const float* __restrict__ Kp,
@@ -59,15 +67,16 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
 }
 
 // stats[0]=mean, [1]=rstd, [2]=a=gamma*rstd, [3]=beta ; updates running stats (momentum, unbiased var)
-__global__ void bn_stats_final_kernel(const float* __restrict__ Kp, const float* __restrict__ part, int nch, int M, int C,
+__global__ __launch_bounds__(1024) void bn_stats_final_kernel(const float* __restrict__ Kp, const float* __restrict__ part, int nch, int M, int C,
                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                       float* __restrict__ rmean, float* __restrict__ rvar, long long* nbt,
                                       float* __restrict__ stats, float eps, float momentum) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && nbt) *nbt += 1;
-  if (c >= C) return;
-  float s1 = 0.f, s2 = 0.f;
-  for (int i = 0; i < nch; ++i) { s1 += part[(long)i * C + c]; s2 += part[(long)(nch + i) * C + c]; }
+  __shared__ float sh[2 * 32 * 32];
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+  int c;
+  float tot[2];
+  if (!chunk_reduce<32, 2>(part, nch, C, sh, c, tot)) return;
+  const float s1 = tot[0], s2 = tot[1];
   const float invM = 1.f / (float)M;
   const float d = s1 * invM;
   const float mean = Kp[c] + d;
@@ -160,14 +169,15 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 }
 
 // dgamma/dbeta (+)= ; coef[0]=gamma*rstd, [1]=dbeta/M, [2]=dgamma/M
-__global__ void bn_bwd_final_kernel(const float* __restrict__ part, int nch, int M, int C,
+__global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const float* __restrict__ part, int nch, int M, int C,
                                     const float* __restrict__ gamma, const float* __restrict__ stats,
                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef,
                                     int accumulate) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s1 = 0.f, s2 = 0.f;
-  for (int i = 0; i < nch; ++i) { s1 += part[(long)i * C + c]; s2 += part[(long)(nch + i) * C + c]; }
+  __shared__ float sh[2 * 32 * 32];
+  int c;
+  float tot[2];
+  if (!chunk_reduce<32, 2>(part, nch, C, sh, c, tot)) return;
+  const float s1 = tot[0], s2 = tot[1];
   if (dbeta) dbeta[c] = accumulate ? dbeta[c] + s1 : s1;
   if (dgamma) dgamma[c] = accumulate ? dgamma[c] + s2 : s2;
   const float invM = 1.f / (float)M;
@@ -307,11 +317,11 @@ extern "C" int stil_bn_train_fwd(const float* x, const float* gamma, const float
   float* pilot = workspace + (size_t)2 * nch * C;
   int rpc = cdiv(M, nch);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_pilot_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, x, pilot, M, C);
+  hipLaunchKernelGGL(bn_pilot_kernel, dim3(cdiv(C, 32)), dim3(256), 0, s, x, pilot, M, C);
   STIL_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C / ct, nch), dim3(256), 0, s, x, pilot, workspace, M, C, ct, rpc);
   STIL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, pilot, workspace, nch, M, C, gamma, beta,
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, s, pilot, workspace, nch, M, C, gamma, beta,
                      running_mean, running_var, num_batches_tracked, stats, eps, momentum);
   STIL_LAUNCH_CHECK();
   long total4 = (long)M * C / 4;
@@ -347,7 +357,7 @@ extern "C" int stil_bn_train_bwd(const float* dz, const float* z, const float* x
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C / ct, nch), dim3(256), 0, s, dz, z, x, stats, gout, workspace, M, C,
                      ct, rpc, relu);
   STIL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, workspace, nch, M, C, gamma, stats, dgamma,
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, s, workspace, nch, M, C, gamma, stats, dgamma,
                      dbeta, coef, accumulate);
   STIL_LAUNCH_CHECK();
   long total4 = (long)M * C / 4;

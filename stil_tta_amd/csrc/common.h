@@ -68,6 +68,34 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
   return r;
 }
 
+// Fixed-order reduction of per-chunk partials: a block of 32*LANES threads owns 32 columns; lane l sums chunks
+// l, l+LANES, ... and the LANES lane-sums are added in order (deterministic).  part: [nplanes][nch][C].
+// Returns true in the threads (lane 0) that hold the totals of column c.
+template <int LANES, int NPL>
+__device__ __forceinline__ bool chunk_reduce(const float* __restrict__ part, int nch, int C, float* sh, int& c,
+                                             float (&tot)[NPL]) {
+  const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
+  c = blockIdx.x * 32 + cl;
+  float s[NPL];
+#pragma unroll
+  for (int q = 0; q < NPL; ++q) s[q] = 0.f;
+  if (c < C)
+    for (int i = lane; i < nch; i += LANES)
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) s[q] += part[((long)q * nch + i) * C + c];
+#pragma unroll
+  for (int q = 0; q < NPL; ++q) sh[(q * LANES + lane) * 32 + cl] = s[q];
+  __syncthreads();
+  if (lane != 0 || c >= C) return false;
+#pragma unroll
+  for (int q = 0; q < NPL; ++q) {
+    float t = 0.f;
+    for (int l = 0; l < LANES; ++l) t += sh[(q * LANES + l) * 32 + cl];
+    tot[q] = t;
+  }
+  return true;
+}
+
 // exact (erf) GELU and its derivative: nn.GELU() default.
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {

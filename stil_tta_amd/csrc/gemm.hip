@@ -62,25 +62,34 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-template <int TM, int TN>
+// branch-free 16-byte load: the address is clamped to a valid one and the value selected afterwards, so the
+// compiler can issue every load of a tile up front and wait once, right before the LDS store (a divergent
+// branch per load made it wait vmcnt(0) inside the load block, serialising prefetch and MFMA).
+__device__ __forceinline__ float4 ld4_sel(const float* p, const float* safe, bool ok) {
+  const float4 v = *reinterpret_cast<const float4*>(ok ? p : safe);
+  return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <int TM, int TN, int BK, bool VEC>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
-  constexpr int BM = 64 * TM, BN = 64 * TN, BK = 16, LS = 20;
-  constexpr int RA = BM / 64, RB = BN / 64;
-  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LS];
+  constexpr int BM = 64 * TM, BN = 64 * TN, LS = BK + 4;   // LS = 20 / 36: conflict-free ds_read_b128 (i*LS mod 64 distinct)
+  constexpr int KQ = BK / 4, RP = 256 / KQ;                 // float4 per tile row, tile rows per load pass
+  constexpr int RA = BM / RP, RB = BN / RP;
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 * (BM + BN) * LS floats
   float* As = lds;
   float* Bs = lds + 2 * BM * LS;
 
   const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
   const int wg = xcd_remap(blockIdx.x, nbm * nbn);
   const int tm = wg / nbn, tn = wg - tm * nbn;
-  const int tid = threadIdx.x, kq = tid & 3, r0 = tid >> 2;
+  const int tid = threadIdx.x, kq = tid % KQ, r0 = tid / KQ;
   const ConvGeom g = p.g;
 
   int a_n[RA], a_oy[RA], a_ox[RA];
   bool a_ok[RA];
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
-    int m = tm * BM + r0 + 64 * i;
+    int m = tm * BM + r0 + RP * i;
     a_ok[i] = m < p.M;
     int mm = a_ok[i] ? m : 0;
     int ohw = g.OH * g.OW;
@@ -92,17 +101,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
   bool b_ok[RB];
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
-    int n = tn * BN + r0 + 64 * i;
+    int n = tn * BN + r0 + RP * i;
     b_ok[i] = n < p.N;
     b_ptr[i] = p.Bw + (long)(b_ok[i] ? n : 0) * p.ldb + kq * 4;
   }
 
+  // K is walked tap by tap: the per-row source pointer and validity are recomputed only when the tap changes
+  // (every C/BK iterations); inside a tap an iteration costs one pointer add per load.
   float4 ra[RA], rb[RB];
-  auto gload = [&](int kt) {
-    const int k0 = kt * BK;
-    const int tap = k0 / g.C, c0 = k0 - tap * g.C;
+  const float* a_src[RA];
+  bool a_val[RA];
+  auto set_tap = [&](int tap) {
     const int ky = tap / g.KW, kx = tap - ky * g.KW;
-    const int nval = p.K - (k0 + kq * 4);
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       int iy, ix;
@@ -117,20 +127,39 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
         ok = ok && (iy * g.stride == ty) && (ix * g.stride == tx);
       }
       ok = ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
-      const float* src = p.A + ((long)(a_n[i] * g.H + iy) * g.W + ix) * p.lda + c0 + kq * 4;
-      ra[i] = ok ? ld4_guard(src, nval, p.vecA) : make_float4(0.f, 0.f, 0.f, 0.f);
+      a_val[i] = ok;
+      a_src[i] = ok ? p.A + ((long)(a_n[i] * g.H + iy) * g.W + ix) * p.lda + kq * 4 : p.A;
+    }
+  };
+  int cur_tap = 0, c0 = 0, kb = 0;  // c0: channel offset inside the tap; kb = cur_tap*C + c0 (column of W)
+  const int ntaps = g.KH * g.KW;
+  set_tap(0);
+  auto gload = [&]() {
+    const int nval = g.C - (c0 + kq * 4);   // <= 0 only in the K tail of a plain GEMM (C == K, K % BK != 0)
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      if (VEC) ra[i] = ld4_sel(a_src[i] + c0, p.A, a_val[i] && nval > 0);
+      else ra[i] = a_val[i] ? ld4_guard(a_src[i] + c0, nval, 0) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
-    for (int i = 0; i < RB; ++i)
-      rb[i] = b_ok[i] ? ld4_guard(b_ptr[i] + k0, nval, p.vecB) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < RB; ++i) {
+      if (VEC) rb[i] = ld4_sel(b_ptr[i] + kb, p.Bw, b_ok[i] && nval > 0);
+      else rb[i] = b_ok[i] ? ld4_guard(b_ptr[i] + kb, nval, 0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    c0 += BK; kb += BK;
+    if (c0 >= g.C) {   // block-uniform
+      kb += g.C - c0;  // (plain GEMM tail: keep kb = tap*C)
+      c0 = 0;
+      if (++cur_tap < ntaps) set_tap(cur_tap);
+    }
   };
   auto lstore = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < RA; ++i)
-      *reinterpret_cast<float4*>(&As[buf * BM * LS + (r0 + 64 * i) * LS + kq * 4]) = ra[i];
+      *reinterpret_cast<float4*>(&As[buf * BM * LS + (r0 + RP * i) * LS + kq * 4]) = ra[i];
 #pragma unroll
     for (int i = 0; i < RB; ++i)
-      *reinterpret_cast<float4*>(&Bs[buf * BN * LS + (r0 + 64 * i) * LS + kq * 4]) = rb[i];
+      *reinterpret_cast<float4*>(&Bs[buf * BN * LS + (r0 + RP * i) * LS + kq * 4]) = rb[i];
   };
 
   const int w = tid >> 6, wm = w >> 1, wn = w & 1, lane = tid & 63, li = lane & 31, lh = lane >> 5;
@@ -142,17 +171,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = (p.K + BK - 1) / BK;
-  gload(0);
+  const int nk = ntaps * ((g.C + BK - 1) / BK);
+  gload();
   lstore(0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
+    if (kt + 1 < nk) gload();
     const float* Ab = As + buf * BM * LS + (wm * TM * 32 + li) * LS + lh * 4;
     const float* Bb = Bs + buf * BN * LS + (wn * TN * 32 + li) * LS + lh * 4;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < BK / 8; ++t) {
       float4 a[TM], b[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LS + t * 8);
@@ -211,7 +240,7 @@ struct GemmTNArgs {
   int vecY, vecX;
 };
 
-template <int TNn, int TK>
+template <int TNn, int TK, bool VEC>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p) {
   constexpr int BN = 64 * TNn, BKo = 64 * TK, BMr = 16;
   constexpr int Y4 = BN / 4, X4 = BKo / 4;            // float4 per row
@@ -244,7 +273,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p) {
 #pragma unroll
     for (int i = 0; i < YP; ++i) {
       int m = m0 + yr + YR * i;
-      ry[i] = (m < m_end) ? ld4_guard(p.Y + (long)m * p.ldy + ycol, p.N - ycol, p.vecY) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (VEC) ry[i] = ld4_sel(p.Y + (long)m * p.ldy + ycol, p.Y, m < m_end && ycol < p.N);
+      else ry[i] = (m < m_end) ? ld4_guard(p.Y + (long)m * p.ldy + ycol, p.N - ycol, 0) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
@@ -256,7 +286,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p) {
       int iy = oy * g.stride - g.pad + xky, ix = ox * g.stride - g.pad + xkx;
       ok = ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
       const float* src = p.X + ((long)(n * g.H + iy) * g.W + ix) * p.ldx + xcch;
-      rx[i] = ok ? ld4_guard(src, p.K - xk, p.vecX) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (VEC) rx[i] = ld4_sel(src, p.X, ok);
+      else rx[i] = ok ? ld4_guard(src, p.K - xk, 0) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto lstore = [&](int buf) {
@@ -342,22 +373,29 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ P, float* __restri
 
 // ---------------------------------------------------------------------------------------
 // column sums  out[c] (+)= sum_m X[m, c]   (bias grads).  Stage 1: per row-chunk partials.
-__global__ void colsum_partial_kernel(const float* __restrict__ X, float* __restrict__ part, int M, int N, int ld,
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, float* __restrict__ part, int M, int N, int ld,
                                       int rows_per_chunk) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= N) return;
-  int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
-  float s = 0.f;
-  for (int m = m0; m < m1; ++m) s += X[(long)m * ld + c];
-  part[(long)blockIdx.y * N + c] = s;
+  __shared__ float sh[4 * 64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;  // 64 columns x 4 row lanes
+  const int c = blockIdx.x * 64 + cl;
+  const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
+  float s0 = 0.f, s1 = 0.f;
+  if (c < N) {
+    int m = m0 + rl;
+    for (; m + 4 < m1; m += 8) { s0 += X[(long)m * ld + c]; s1 += X[(long)(m + 4) * ld + c]; }
+    for (; m < m1; m += 4) s0 += X[(long)m * ld + c];
+  }
+  sh[rl * 64 + cl] = s0 + s1;
+  __syncthreads();
+  if (rl == 0 && c < N) part[(long)blockIdx.y * N + c] = sh[cl] + sh[64 + cl] + sh[128 + cl] + sh[192 + cl];
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nchunks, int N,
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nchunks, int N,
                                     int accumulate, float scale) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= N) return;
-  float s = 0.f;
-  for (int i = 0; i < nchunks; ++i) s += part[(long)i * N + c];
-  s *= scale;
+  __shared__ float sh[8 * 32];
+  int c;
+  float tot[1];
+  if (!chunk_reduce<8, 1>(part, nchunks, N, sh, c, tot)) return;
+  const float s = tot[0] * scale;
   out[c] = accumulate ? out[c] + s : s;
 }
 
@@ -373,11 +411,37 @@ static int check_geom(const ConvGeom& g, int vec_required) {
 
 static inline int is_vec(const void* p, int ld) { return (((uintptr_t)p) % 16 == 0) && (ld % 4 == 0); }
 
+static int g_gemm_bk = 16;
+// tuning knob (A/B measurements only): K-depth of the NT kernel's LDS tile, 16 or 32
+extern "C" int stil_set_gemm_bk(int bk) {
+  if (bk != 16 && bk != 32) { stil_set_error("stil_set_gemm_bk: %d not in {16, 32}", bk); return STIL_EINVAL; }
+  g_gemm_bk = bk;
+  return STIL_OK;
+}
+static bool g_nt_attr = false;
+static int gemm_nt_attr() {
+  if (g_nt_attr) return STIL_OK;
+  hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<2, 2, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  if (e != hipSuccess) { stil_set_error("gemm_nt: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return STIL_EHIP; }
+  g_nt_attr = true;
+  return STIL_OK;
+}
+
 // which tile variant stil_gemm_nt launches for an [M,N] output: 22 = 128x128, 21 = 128x64, 11 = 64x64 block tile
+static int g_force_variant = 0;
+// tuning knob (A/B measurements only): force the tile variant (11, 21, 22) or 0 = automatic
+extern "C" int stil_set_gemm_variant(int v) {
+  if (v != 0 && v != 11 && v != 21 && v != 22) { stil_set_error("stil_set_gemm_variant: bad variant %d", v); return STIL_EINVAL; }
+  g_force_variant = v;
+  return STIL_OK;
+}
 extern "C" int stil_gemm_nt_variant(int M, int N) {
+  if (g_force_variant) return g_force_variant;
+  // measured (tests/tools/gemm_bench.py): fp32 MFMA is slow enough that 64x64 / 128x64 block tiles lose nothing to
+  // 128x128 in operand reuse and win on occupancy + tile quantization over 256 CUs.
   if (N <= 64) return M <= 4096 ? 11 : 21;
-  if ((long)cdiv(M, 128) * cdiv(N, 128) < 128) return 11;
-  return 22;
+  if (N >= 1024 && M >= 8192) return 21;
+  return 11;
 }
 
 extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, int lda, int ldb, int ldc,
@@ -399,16 +463,20 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int variant = stil_gemm_nt_variant(M, N);
-  if (variant == 11) {
-    dim3 grid(cdiv(M, 64) * cdiv(N, 64));
-    hipLaunchKernelGGL((gemm_nt_kernel<1, 1>), grid, dim3(256), 0, s, p);
-  } else if (variant == 21) {
-    dim3 grid(cdiv(M, 128) * cdiv(N, 64));
-    hipLaunchKernelGGL((gemm_nt_kernel<2, 1>), grid, dim3(256), 0, s, p);
-  } else {
-    dim3 grid(cdiv(M, 128) * cdiv(N, 128));
-    hipLaunchKernelGGL((gemm_nt_kernel<2, 2>), grid, dim3(256), 0, s, p);
-  }
+  // BK = 32 halves the barriers per MFMA and doubles the latency cover of the register prefetch; needs whole taps
+  const bool bk32 = g_gemm_bk == 32 && (K % 32 == 0) && (KH * KW == 1 || srcC % 32 == 0);
+  rc = gemm_nt_attr();
+  if (rc) return rc;
+  const bool vec = p.vecA && p.vecB && (K % 4 == 0);  // every 16-byte load is aligned and entirely in or out
+#define LAUNCH_NT(TM_, TN_, BK_, V_)                                                                          \
+  hipLaunchKernelGGL((gemm_nt_kernel<TM_, TN_, BK_, V_>), dim3(cdiv(M, 64 * TM_) * cdiv(N, 64 * TN_)), dim3(256), \
+                     (size_t)2 * 64 * (TM_ + TN_) * (BK_ + 4) * sizeof(float), s, p)
+  if (!vec) {  // unaligned / ragged operands (K = 286 classifier gradients ...): scalar guarded loads
+    if (variant == 11) LAUNCH_NT(1, 1, 16, false); else if (variant == 21) LAUNCH_NT(2, 1, 16, false); else LAUNCH_NT(2, 2, 16, false);
+  } else if (variant == 11) { if (bk32) LAUNCH_NT(1, 1, 32, true); else LAUNCH_NT(1, 1, 16, true); }
+  else if (variant == 21) { if (bk32) LAUNCH_NT(2, 1, 32, true); else LAUNCH_NT(2, 1, 16, true); }
+  else { if (bk32) LAUNCH_NT(2, 2, 32, true); else LAUNCH_NT(2, 2, 16, true); }
+#undef LAUNCH_NT
   STIL_LAUNCH_CHECK();
   return STIL_OK;
 }
@@ -446,12 +514,15 @@ extern "C" int stil_wgrad_tn(const float* dY, const float* X, float* dW, int M, 
   p.vecY = is_vec(dY, ldy);
   p.vecX = is_vec(X, ldx) && (srcC % 4 == 0);
   hipStream_t s = (hipStream_t)stream;
+  const bool vec = p.vecY && p.vecX && (N % 4 == 0) && (K % 4 == 0);
   if (N <= 64) {
     dim3 grid(cdiv(N, 64) * cdiv(K, 128), 1, splits);
-    hipLaunchKernelGGL((gemm_tn_kernel<1, 2>), grid, dim3(256), 0, s, p);
+    if (vec) hipLaunchKernelGGL((gemm_tn_kernel<1, 2, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_tn_kernel<1, 2, false>), grid, dim3(256), 0, s, p);
   } else {
     dim3 grid(cdiv(N, 128) * cdiv(K, 128), 1, splits);
-    hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), grid, dim3(256), 0, s, p);
+    if (vec) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, false>), grid, dim3(256), 0, s, p);
   }
   STIL_LAUNCH_CHECK();
   long total = (long)N * K;
@@ -463,19 +534,19 @@ extern "C" int stil_wgrad_tn(const float* dY, const float* X, float* dW, int M, 
 }
 
 extern "C" size_t stil_colsum_workspace_bytes(int M, int N) {
-  int rpc = 512;
+  int rpc = 128;
   return (size_t)cdiv(M, rpc) * N * sizeof(float);
 }
 
 extern "C" int stil_colsum(const float* X, float* out, int M, int N, int ld, int accumulate, float scale,
                            float* workspace, size_t workspace_bytes, void* stream) {
   STIL_REQUIRE(X && out && workspace && M > 0 && N > 0, "stil_colsum: null pointer or empty shape");
-  int rpc = 512, nch = cdiv(M, rpc);
+  int rpc = 128, nch = cdiv(M, rpc);
   STIL_REQUIRE(workspace_bytes >= (size_t)nch * N * sizeof(float), "stil_colsum: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), nch), dim3(64), 0, s, X, workspace, M, N, ld, rpc);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), nch), dim3(256), 0, s, X, workspace, M, N, ld, rpc);
   STIL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 64)), dim3(64), 0, s, workspace, out, nch, N, accumulate, scale);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 32)), dim3(256), 0, s, workspace, out, nch, N, accumulate, scale);
   STIL_LAUNCH_CHECK();
   return STIL_OK;
 }

@@ -36,7 +36,7 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     with pytest.raises(RuntimeError, match="multiple of 4"):
         L.ema_update(ctypes.c_void_p(16), ctypes.c_void_p(32), 6, 0.9, None)
     assert L.wgrad_workspace_bytes(1 << 20, 64, 576) > 0
-    assert L.gemm_nt_variant(3211264, 256) == 22 and L.gemm_nt_variant(256, 286) == 11 and L.gemm_nt_variant(802816, 64) == 21
+    assert L.gemm_nt_variant(50176, 1024) == 21 and L.gemm_nt_variant(256, 286) == 11 and L.gemm_nt_variant(802816, 64) == 21
 
 
 def test_ops_refuse_cpu_tensors_no_fallback():

@@ -1,0 +1,48 @@
+"""Micro-benchmark (GPU box) of the NT / TN GEMM kernels on the step's dominant shapes; A/B knobs in one process.
+usage: python tests/tools/gemm_bench.py [rounds]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from stil_tta_amd import ops
+from stil_tta_amd._lib import lib
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+L = lib()
+dev = "cuda"
+# (M, N, K, k, stride, mode, H)  -- H = source spatial size for conv gathers
+NT = [(50176, 256, 2304, 3, 1, 0, 14), (802816, 256, 64, 1, 1, 0, 56), (50176, 1024, 256, 1, 1, 0, 14), (16640, 512, 2048, 1, 1, 0, 0),
+      (200704, 512, 128, 1, 1, 0, 28), (16640, 2048, 512, 1, 1, 0, 0), (802816, 64, 576, 3, 1, 0, 56), (200704, 128, 1152, 3, 1, 0, 28),
+      (12544, 512, 4608, 3, 1, 0, 7), (802816, 64, 256, 1, 1, 0, 56)]
+
+def run_nt(shape):
+    M, N, K, k, s, mode, H = shape
+    if k == 1:
+        A = torch.randn(M, K, device=dev); geom = None
+    else:
+        C = K // (k * k); Nb = M // (H * H)
+        A = torch.randn(Nb, H, H, C, device=dev); geom = (H, H, C, H, H, k, k, s, 1, 0)
+    W = torch.randn(N, K, device=dev)
+    out = torch.empty(M, N, device=dev)
+    ops.gemm_nt(A, W, M, N, K, geom=geom, out=out)
+    torch.cuda.synchronize()
+    s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s0.record()
+    for _ in range(rounds):
+        ops.gemm_nt(A, W, M, N, K, geom=geom, out=out)
+    e0.record(); torch.cuda.synchronize()
+    ms = s0.elapsed_time(e0) / rounds
+    return ms, 2.0 * M * N * K / ms / 1e9
+
+NT += [(50176, 256, 1024, 1, 1, 0, 14), (12544, 512, 2048, 1, 1, 0, 7), (12544, 2048, 512, 1, 1, 0, 7), (50176, 1024, 256, 1, 1, 0, 14)]
+variants = [("v22", lambda: L.set_gemm_variant(22)), ("v21", lambda: L.set_gemm_variant(21)), ("v11", lambda: L.set_gemm_variant(11))]
+res = {}
+for r in range(2):  # interleaved rounds
+    for name, setter in variants:
+        setter()
+        for sh in NT:
+            ms, tf = run_nt(sh)
+            res.setdefault((name, sh), []).append(tf)
+print(f"{'shape':46s} " + " ".join(f"{n:>10s}" for n, _ in variants))
+for sh in NT:
+    print(f"{str(sh):46s} " + " ".join(f"{max(res[(n, sh)]):10.1f}" for n, _ in variants))
+L.set_gemm_variant(0)
