@@ -155,11 +155,11 @@ def main():
             print(f"  sum of C-ABI kernels {tot:.3f} ms of {dt / a.steps * 1e3:.3f} ms/step", file=sys.stderr)
             shapes = {}
             for name, ms, meta in prof:
-                if name == "gemm_nt":
+                if name in ("gemm_nt", "wgrad_tn") and meta:
                     c = shapes.setdefault(meta[2], [0, 0.0, 0.0])
                     c[0] += 1; c[1] += ms; c[2] += meta[1]
-            print("  gemm_nt by shape (M, N, K, k, stride, mode): launches, ms, TFLOP/s", file=sys.stderr)
-            for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:40]:
+            print("  gemm by shape (M, N, K, k, stride, mode; mode 2 = wgrad_tn): launches, ms, TFLOP/s", file=sys.stderr)
+            for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:60]:
                 print(f"    {str(k):44s} {v[0]:3d} {v[1]:8.3f} ms {v[2] / v[1] / 1e9:7.1f} TF", file=sys.stderr)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(fl, a.classes, a.img, a.cpu_batch)

@@ -33,11 +33,15 @@ int stil_device_count(void);
  * Agather row m = (n, oy, ox) over an NHWC source [*, srcH, srcW, srcC] (row stride lda),
  * k = (ky*KW + kx)*srcC + c.  mode 0: iy = oy*stride - pad + ky (forward);  mode 1: iy = (oy + pad - ky)/stride
  * when divisible (input-gradient of a strided conv).  A plain GEMM is srcH=srcW=OH=OW=KH=KW=1, srcC=K.
+ * Output row map: row m = (n, oy, ox) is written to row (n*out_OH + oy*out_stride + out_py)*out_OW + ox*out_stride + out_px
+ * (out_stride 1 = identity): the input-gradient of a stride-s conv is s*s such launches, one per output phase, each a
+ * stride-1 gather over its own tap subset (stil_conv_weight_layout_phase) -- no multiply-by-zero work.
  * `pre` (optional) receives the value before the activation.  act: 0 none, 1 ReLU, 2 GELU(erf).
  * Replaces nn.Conv2d / nn.Linear forward and input-gradient: models/resnets.py:112-132,248-260,
  * models/Transformer.py:27-33,63-88, STiLModel_backbone.py:19-32,139,153-155. */
 int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, int lda, int ldb, int ldc,
-                 int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad, int mode,
+                 int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad_y, int pad_x,
+                 int mode, int out_stride, int out_py, int out_px, int out_OH, int out_OW,
                  const float* bias, const float* sub, const float* scale, const float* shift, const float* resid,
                  int ldr, float* pre, int act, float alpha, void* stream);
 
@@ -62,6 +66,9 @@ int stil_colsum(const float* X, float* out, int M, int N, int ld, int accumulate
 /* (Cout,Cin,KH,KW) -> [Cout][KH*KW][Cin] (forward operand) and [Cin][KH*KW][Cout] (dgrad operand) */
 int stil_conv_weight_layout(const float* w, float* w_fwd, float* w_dgrad, int Cout, int Cin, int KH, int KW,
                             void* stream);
+/* dgrad phase operand: w_sub[ci][ky'][kx'][co] = w[co][ci][ky0 + s*(KHs-1-ky')][kx0 + s*(KWs-1-kx')] */
+int stil_conv_weight_layout_phase(const float* w, float* w_sub, int Cout, int Cin, int KH, int KW, int stride,
+                                  int ky0, int kx0, int KHs, int KWs, void* stream);
 int stil_im2col_nchw(const float* x, float* col, int N, int Cin, int H, int W, int OH, int OW, int KH,
                      int KW, int stride, int pad, int Kp, void* stream);
 int stil_transpose(const float* in, float* out, int R, int C, void* stream);

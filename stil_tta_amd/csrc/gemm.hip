@@ -20,7 +20,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct ConvGeom {
   int H, W, C;    // source NHWC dims (rows of the source have stride ld)
   int OH, OW;     // the GEMM row index m enumerates (n, oy, ox)
-  int KH, KW, stride, pad;
+  int KH, KW, stride, pad_y, pad_x;
   int mode;       // 0: forward gather  iy = oy*stride - pad + ky ; 1: dgrad gather  iy = (oy + pad - ky)/stride
 };
 
@@ -41,6 +41,9 @@ struct GemmNTArgs {
   int act;  // 0 none, 1 relu, 2 gelu
   float alpha;
   int vecA, vecB;  // 1: 16-byte aligned rows -> float4 loads
+  // output row map: GEMM row m = (n, oy', ox') over the OHxOW grid is written to row
+  // (n*oOH + oy'*os + opy)*oOW + ox'*os + opx of C (os == 1: identity).  Used by the phase-decomposed strided dgrad.
+  int os, opy, opx, oOH, oOW;
 };
 
 __device__ __forceinline__ float4 ld4_guard(const float* p, int nvalid, int vec) {
@@ -118,10 +121,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
       int iy, ix;
       bool ok = a_ok[i];
       if (g.mode == 0) {
-        iy = a_oy[i] * g.stride - g.pad + ky;
-        ix = a_ox[i] * g.stride - g.pad + kx;
+        iy = a_oy[i] * g.stride - g.pad_y + ky;
+        ix = a_ox[i] * g.stride - g.pad_x + kx;
       } else {
-        int ty = a_oy[i] + g.pad - ky, tx = a_ox[i] + g.pad - kx;
+        int ty = a_oy[i] + g.pad_y - ky, tx = a_ox[i] + g.pad_x - kx;
         ok = ok && ty >= 0 && tx >= 0;
         iy = ty / g.stride; ix = tx / g.stride;
         ok = ok && (iy * g.stride == ty) && (ix * g.stride == tx);
@@ -214,15 +217,22 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = tm * BM + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row >= p.M) continue;
+        const int row_m = tm * BM + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row_m >= p.M) continue;
+        long row = row_m;
+        if (p.os != 1) {
+          const int ohw = g.OH * g.OW;
+          const int n = row_m / ohw, rem = row_m - n * ohw;
+          const int oy = rem / g.OW, ox = rem - oy * g.OW;
+          row = ((long)n * p.oOH + oy * p.os + p.opy) * p.oOW + ox * p.os + p.opx;
+        }
         float v = acc[i][j][r] * p.alpha;
         v = (v - sb) * sc + sh + bia;
-        if (p.resid) v += p.resid[(long)row * p.ldr + col];
-        if (p.pre) p.pre[(long)row * p.ldc + col] = v;
+        if (p.resid) v += p.resid[row * p.ldr + col];
+        if (p.pre) p.pre[row * p.ldc + col] = v;
         if (p.act == 1) v = fmaxf(v, 0.f);
         else if (p.act == 2) v = gelu_f(v);
-        p.C[(long)row * p.ldc + col] = v;
+        p.C[row * p.ldc + col] = v;
       }
     }
   }
@@ -268,6 +278,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p) {
   const int ohw = g.OH * g.OW;
 
   float4 ry[YP], rx[XP];
+  // row decode (m -> n, oy, ox) is done once and then advanced incrementally by BMr rows per iteration
+  const bool plain = (g.KH * g.KW == 1) && g.stride == 1 && g.pad_y == 0 && g.pad_x == 0 && g.OH == g.H && g.OW == g.W;
+  int x_n[XP], x_oy[XP], x_ox[XP];
+#pragma unroll
+  for (int i = 0; i < XP; ++i) {
+    int m = m_begin + xr + XR * i;
+    int n = m / ohw, rem = m - n * ohw;
+    x_n[i] = n; x_oy[i] = rem / g.OW; x_ox[i] = rem - x_oy[i] * g.OW;
+  }
   auto gload = [&](int mt) {
     const int m0 = m_begin + mt * BMr;
 #pragma unroll
@@ -280,12 +299,16 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p) {
     for (int i = 0; i < XP; ++i) {
       int m = m0 + xr + XR * i;
       bool ok = m < m_end && xk < p.K;
-      int mm = ok ? m : 0;
-      int n = mm / ohw, rem = mm - n * ohw;
-      int oy = rem / g.OW, ox = rem - oy * g.OW;
-      int iy = oy * g.stride - g.pad + xky, ix = ox * g.stride - g.pad + xkx;
-      ok = ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
-      const float* src = p.X + ((long)(n * g.H + iy) * g.W + ix) * p.ldx + xcch;
+      const float* src;
+      if (plain) {
+        src = p.X + (long)m * p.ldx + xcch;
+      } else {
+        int iy = x_oy[i] * g.stride - g.pad_y + xky, ix = x_ox[i] * g.stride - g.pad_x + xkx;
+        ok = ok && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+        src = p.X + ((long)(x_n[i] * g.H + iy) * g.W + ix) * p.ldx + xcch;
+        x_ox[i] += BMr;
+        while (x_ox[i] >= g.OW) { x_ox[i] -= g.OW; if (++x_oy[i] == g.OH) { x_oy[i] = 0; ++x_n[i]; } }
+      }
       if (VEC) rx[i] = ld4_sel(src, p.X, ok);
       else rx[i] = ok ? ld4_guard(src, p.K - xk, 0) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -445,8 +468,9 @@ extern "C" int stil_gemm_nt_variant(int M, int N) {
 }
 
 extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, int lda, int ldb, int ldc,
-                            int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad,
-                            int mode, const float* bias, const float* sub, const float* scale,
+                            int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad_y,
+                            int pad_x, int mode, int out_stride, int out_py, int out_px, int out_OH, int out_OW,
+                            const float* bias, const float* sub, const float* scale,
                             const float* shift, const float* resid, int ldr, float* pre, int act, float alpha,
                             void* stream) {
   STIL_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0, "stil_gemm_nt: null pointer or empty shape (M=%d N=%d K=%d)", M, N, K);
@@ -454,7 +478,8 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   STIL_REQUIRE(M % (OH * OW) == 0, "stil_gemm_nt: M=%d not a multiple of OH*OW=%d", M, OH * OW);
   GemmNTArgs p;
   p.A = A; p.Bw = W; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-  p.g = ConvGeom{srcH, srcW, srcC, OH, OW, KH, KW, stride, pad, mode};
+  p.g = ConvGeom{srcH, srcW, srcC, OH, OW, KH, KW, stride, pad_y, pad_x, mode};
+  p.os = out_stride < 1 ? 1 : out_stride; p.opy = out_py; p.opx = out_px; p.oOH = out_OH; p.oOW = out_OW;
   p.bias = bias; p.sub = sub; p.scale = scale; p.shift = shift; p.resid = resid; p.ldr = ldr; p.pre = pre; p.act = act;
   p.alpha = alpha;
   p.vecA = is_vec(A, lda) && (srcC % 4 == 0);
@@ -507,7 +532,7 @@ extern "C" int stil_wgrad_tn(const float* dY, const float* X, float* dW, int M, 
   STIL_REQUIRE(workspace_bytes >= (size_t)splits * N * K * sizeof(float), "stil_wgrad_tn: workspace too small");
   GemmTNArgs p;
   p.Y = dY; p.X = X; p.P = workspace; p.M = M; p.N = N; p.K = K; p.ldy = ldy; p.ldx = ldx;
-  p.g = ConvGeom{srcH, srcW, srcC, OH, OW, KH, KW, stride, pad, 0};
+  p.g = ConvGeom{srcH, srcW, srcC, OH, OW, KH, KW, stride, pad, pad, 0};
   int mps = cdiv(M, splits);
   mps = ((mps + 15) / 16) * 16;
   p.m_per_split = mps;

@@ -333,6 +333,21 @@ __global__ void conv_w_layout_kernel(const float* __restrict__ w, float* __restr
   }
 }
 
+// phase (py,px) of a stride-s dgrad:  wsub[ci][ky'][kx'][co] = w[co][ci][ky0 + s*(KHs-1-ky')][kx0 + s*(KWs-1-kx')]
+__global__ void conv_w_phase_kernel(const float* __restrict__ w, float* __restrict__ wsub, int Cout, int Cin, int KH,
+                                    int KW, int s, int ky0, int kx0, int KHs, int KWs) {
+  long total = (long)Cin * KHs * KWs * Cout;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int co = (int)(i % Cout);
+    long t = i / Cout;
+    int kx = (int)(t % KWs); t /= KWs;
+    int ky = (int)(t % KHs);
+    int ci = (int)(t / KHs);
+    int sy = ky0 + s * (KHs - 1 - ky), sx = kx0 + s * (KWs - 1 - kx);
+    wsub[i] = w[(((long)co * Cin + ci) * KH + sy) * KW + sx];
+  }
+}
+
 // ---------------------------------------------------------------- tabular embedding
 // h[b,0]=cls ; h[b,1+j]=cat_emb[int(x[b,j])+off[j]] (j<ncat) ; h[b,1+j]=x[b,j]*w+bias (j>=ncat) ; + colemb[t]
 __global__ void tab_embed_fwd_kernel(const float* __restrict__ x, const int* __restrict__ offs,
@@ -559,6 +574,17 @@ extern "C" int stil_conv_weight_layout(const float* w, float* w_fwd, float* w_dg
   long total = (long)Cout * Cin * KH * KW;
   hipLaunchKernelGGL(conv_w_layout_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w, w_fwd, w_dgrad,
                      Cout, Cin, KH * KW);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" int stil_conv_weight_layout_phase(const float* w, float* w_sub, int Cout, int Cin, int KH, int KW, int stride,
+                                             int ky0, int kx0, int KHs, int KWs, void* stream) {
+  STIL_REQUIRE(w && w_sub && KHs > 0 && KWs > 0 && ky0 + stride * (KHs - 1) < KH && kx0 + stride * (KWs - 1) < KW,
+               "stil_conv_weight_layout_phase: bad arguments");
+  long total = (long)Cin * KHs * KWs * Cout;
+  hipLaunchKernelGGL(conv_w_phase_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w, w_sub, Cout, Cin, KH,
+                     KW, stride, ky0, kx0, KHs, KWs);
   STIL_LAUNCH_CHECK();
   return STIL_OK;
 }

@@ -68,21 +68,26 @@ def _grad_into(param: torch.Tensor, writer):
 
 # ------------------------------------------------------------------------------------------ raw wrappers
 def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None, bias=None, sub=None, scale=None, shift=None,
-            resid=None, pre=None, act=0, alpha=1.0):
-    """C = epilogue(alpha * Agather . W^T).  geom = (srcH, srcW, srcC, OH, OW, KH, KW, stride, pad, mode)."""
+            resid=None, pre=None, act=0, alpha=1.0, pads=None, outmap=None, out_rows=None):
+    """C = epilogue(alpha * Agather . W^T).  geom = (srcH, srcW, srcC, OH, OW, KH, KW, stride, pad, mode);
+    pads = (pad_y, pad_x) overrides geom's pad; outmap = (out_stride, py, px, out_OH, out_OW) scatters GEMM row
+    (n, oy, ox) to output row (n*out_OH + oy*s + py)*out_OW + ox*s + px (out_rows = rows of `out` then)."""
     if geom is None:
         geom = (1, 1, K, 1, 1, 1, 1, 1, 0, 0)
+    pads = (geom[8], geom[8]) if pads is None else pads
+    outmap = (1, 0, 0, geom[3], geom[4]) if outmap is None else outmap
     lda = geom[2] if lda is None else lda
     ldb = K if ldb is None else ldb
     ldc = N if ldc is None else ldc
     if out is None:
-        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+        out = torch.empty((M if out_rows is None else out_rows, N), dtype=torch.float32, device=A.device)
     L = lib()
     meta = None
     if L._prof is not None:  # bench bookkeeping: tile variant + ALGORITHMIC flops (strided dgrad gathers count the conv's flops)
         s2 = geom[7] * geom[7] if geom[9] == 1 else 1
         meta = (L.gemm_nt_variant(M, N), 2.0 * M * N * K / s2, (M, N, K, geom[5], geom[7], geom[9]))
-    L.gemm_nt(_p(A), _p(W), _p(out), M, N, K, lda, ldb, ldc, *geom, _p(bias), _p(sub), _p(scale), _p(shift), _p(resid),
+    L.gemm_nt(_p(A), _p(W), _p(out), M, N, K, lda, ldb, ldc, *geom[:8], pads[0], pads[1], geom[9], *outmap,
+              _p(bias), _p(sub), _p(scale), _p(shift), _p(resid),
               (ldc if resid is not None else 0), _p(pre), act, float(alpha), _stream(), meta=meta)
     return out
 
@@ -95,7 +100,9 @@ def wgrad_tn(dY, X, dW, M, N, K, *, ldy=None, ldx=None, geom=None, Kdst=None, ac
     Kdst = K if Kdst is None else Kdst
     nb = lib().wgrad_workspace_bytes(M, N, K)
     w = _ws.get(nb, dY.device)
-    lib().wgrad_tn(_p(dY), _p(X), _p(dW), M, N, K, ldy, ldx, *geom, Kdst, accumulate, _p(w), nb, _stream())
+    L = lib()
+    meta = (0, 2.0 * M * N * K, (M, N, K, geom[5], geom[7], 2)) if L._prof is not None else None
+    L.wgrad_tn(_p(dY), _p(X), _p(dW), M, N, K, ldy, ldx, *geom, Kdst, accumulate, _p(w), nb, _stream(), meta=meta)
 
 
 def colsum(X, out, M, N, *, ld=None, accumulate=0, scale=1.0):
@@ -272,15 +279,46 @@ class ConvBnActFn(torch.autograd.Function):
                 if k == 1 and stride == 1:
                     wd = transpose(w.reshape(Cout, Cin))  # [Cin, Cout]
                     dx = gemm_nt(dy, wd, M, Cin, Cout).view(Nb, H, W_, Cin)
-                else:
+                elif stride == 1:
                     wd = torch.empty((Cin, k * k * Cout), dtype=torch.float32, device=dev)
                     lib().conv_weight_layout(_p(w), None, _p(wd), Cout, Cin, k, k, _stream())
                     g2 = (OH, OW, Cout, H, W_, k, k, stride, pad, 1)
                     dx = gemm_nt(dy, wd, Nb * H * W_, Cin, k * k * Cout, geom=g2).view(Nb, H, W_, Cin)
+                else:
+                    dx = strided_dgrad(dy, w, Nb, H, W_, Cin, OH, OW, Cout, k, stride, pad)
             gw = geom[:9]
             dw = _grad_into(w, lambda dst, a: wgrad_tn(dy, x, dst, M, Cout, k * k * Cin, geom=gw, accumulate=a))
         return (dx, dw, (None if gslot is not None else dgamma), (None if bslot is not None else dbeta), None, None, None,
                 dres, None, None, None, None, None)
+
+
+def strided_dgrad(dy, w, Nb, H, W_, Cin, OH, OW, Cout, k, stride, pad):
+    """Input gradient of a stride-s conv as s*s stride-1 gathers, one per output phase (py, px): phase pixels
+    (s*oy'+py, s*ox'+px) only see taps ky = ky0 + s*j with ky0 = (py+pad) % s, so no multiply-by-zero work is done
+    (the generic mode-1 gather computes s*s times the algorithmic MACs)."""
+    dev = dy.device
+    dx = torch.zeros((Nb * H * W_, Cin), dtype=torch.float32, device=dev)  # phases without taps (1x1 s2) stay zero
+    for py in range(stride):
+        ky0 = (py + pad) % stride
+        KHs = len(range(ky0, k, stride))
+        Hs = len(range(py, H, stride))
+        if KHs == 0 or Hs == 0:
+            continue
+        dy0 = (py + pad - ky0) // stride
+        for px in range(stride):
+            kx0 = (px + pad) % stride
+            KWs = len(range(kx0, k, stride))
+            Ws = len(range(px, W_, stride))
+            if KWs == 0 or Ws == 0:
+                continue
+            dx0 = (px + pad - kx0) // stride
+            wsub = torch.empty((Cin, KHs * KWs * Cout), dtype=torch.float32, device=dev)
+            lib().conv_weight_layout_phase(_p(w), _p(wsub), Cout, Cin, k, k, stride, ky0, kx0, KHs, KWs, _stream())
+            # iy = oy' + dy0 - jy = oy' - pad' + ky'  with ky' = KHs-1-jy, pad' = KHs-1-dy0
+            geom = (OH, OW, Cout, Hs, Ws, KHs, KWs, 1, 0, 0)
+            gemm_nt(dy, wsub, Nb * Hs * Ws, Cin, KHs * KWs * Cout, geom=geom, out=dx, pads=(KHs - 1 - dy0, KWs - 1 - dx0),
+                    outmap=(stride, py, px, H, W_))
+    return dx.view(Nb, H, W_, Cin)
 
 
 def conv_bn_eval(x, w, gamma, beta, rmean, rvar, resid, k, stride, pad, relu, stem=None):

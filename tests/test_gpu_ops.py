@@ -89,6 +89,20 @@ def test_conv_fwd_dgrad_wgrad(ops, Cin, Cout, k, stride, pad, H):
     close(dw, 2 * w.grad, name="conv wgrad accumulate")
 
 
+@pytest.mark.parametrize("Cin,Cout,k,stride,pad,H,W", [(32, 64, 3, 2, 1, 14, 14), (64, 128, 1, 2, 0, 14, 10), (16, 32, 3, 2, 1, 7, 9), (32, 32, 3, 2, 1, 8, 6)])
+def test_strided_dgrad_phase_decomposition(ops, Cin, Cout, k, stride, pad, H, W):
+    g = torch.Generator().manual_seed(H * W)
+    Nb = 3
+    x = torch.randn(Nb, Cin, H, W, generator=g, requires_grad=True)
+    w = torch.randn(Cout, Cin, k, k, generator=g)
+    y = F.conv2d(x, w, stride=stride, padding=pad)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    OH, OW = y.shape[2], y.shape[3]
+    dx = ops.strided_dgrad(nhwc(gy).view(-1, Cout), dev(w), Nb, H, W, Cin, OH, OW, Cout, k, stride, pad)
+    close(nchw(dx), x.grad, name="strided dgrad")
+
+
 @pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False)])
 @pytest.mark.parametrize("Cin,Cout,k,stride,pad,H", [(64, 64, 3, 1, 1, 8), (64, 128, 1, 2, 0, 8), (128, 256, 1, 1, 0, 6)])
 def test_conv_bn_act_train_and_eval(ops, Cin, Cout, k, stride, pad, H, relu, res):
