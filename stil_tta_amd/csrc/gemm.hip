@@ -14,6 +14,7 @@
 // for every 16-lane group (i*20 mod 64 distinct multiples of 4), and one b128 read feeds
 // four MFMA k-steps.  The k order inside a 8-wide group is permuted identically for A and B.
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -175,34 +176,52 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = ntaps * ((g.C + BK - 1) / BK);
-  gload();
-  lstore(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) gload();
-    const float* Ab = As + buf * BM * LS + (wm * TM * 32 + li) * LS + lh * 4;
-    const float* Bb = Bs + buf * BN * LS + (wn * TN * 32 + li) * LS + lh * 4;
+  // Interior fast path (block-uniform): single-tap gathers (plain GEMM, 1x1 conv) whose tile lies fully inside M x N
+  // and whose K is a multiple of BK need no predicate at all -> unconditional 16-byte loads, pointer += BK.
+  const bool full = VEC && ntaps == 1 && g.mode == 0 && (g.C % BK == 0) && (tm + 1) * BM <= p.M && (tn + 1) * BN <= p.N;
+  auto mainloop = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    auto load = [&]() {
+      if constexpr (FULL) {
 #pragma unroll
-    for (int t = 0; t < BK / 8; ++t) {
-      float4 a[TM], b[TN];
+        for (int i = 0; i < RA; ++i) ra[i] = *reinterpret_cast<const float4*>(a_src[i] + c0);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LS + t * 8);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LS + t * 8);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-        }
-    }
-    if (kt + 1 < nk) lstore(buf ^ 1);
+        for (int i = 0; i < RB; ++i) rb[i] = *reinterpret_cast<const float4*>(b_ptr[i] + c0);
+        c0 += BK;
+      } else {
+        gload();
+      }
+    };
+    load();
+    lstore(0);
     __syncthreads();
-  }
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) load();
+      const float* Ab = As + buf * BM * LS + (wm * TM * 32 + li) * LS + lh * 4;
+      const float* Bb = Bs + buf * BN * LS + (wn * TN * 32 + li) * LS + lh * 4;
+#pragma unroll
+      for (int t = 0; t < BK / 8; ++t) {
+        float4 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LS + t * 8);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LS + t * 8);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+          }
+      }
+      if (kt + 1 < nk) lstore(buf ^ 1);
+      __syncthreads();
+    }
+  };
+  if (full) mainloop(std::true_type{}); else mainloop(std::false_type{});
 
   // epilogue: C/D map of 32x32 tiles: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
