@@ -113,7 +113,7 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    loss = float(m.last["loss"])
+    loss = float(m.last["loss"].detach())
     assert loss == loss, "loss is NaN"
 
     if rank == 0:
@@ -131,6 +131,16 @@ def main():
                     unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
                     launches_per_step=nl, avg_launch_us=round(tsum / max(1, nl) * 1e6, 2),
                     flops_per_step=fsum, share_of_step_time=round(tsum / (dt / a.steps), 4))
+        # HBM traffic of that kernel: PMC counters cannot be read from inside the process; the latest separate-pass
+        # rocprofv3 measurement of this same command is kept under profiles/ and quoted when it is for this kernel.
+        try:
+            pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_traffic.json"))
+            tj = json.load(open(os.path.join(ROOT, "profiles", pmc[-1]))) if pmc else None
+            if tj and tj["kernel"] == kname and a.batch == 256 and a.img == 224:
+                roof["traffic"] = round(tj["bytes_per_launch"])
+                roof["traffic_source"] = "profiles/" + pmc[-1]
+        except Exception:
+            pass
         fps = FLOPS_PER_SAMPLE.get((a.img, a.ncat + a.ncon))
         out = dict(metric="training samples/sec (labeled+unlabeled) for DVM STiL", value=round(value, 2), unit="samples/s",
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3),
