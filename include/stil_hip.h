@@ -127,6 +127,26 @@ int stil_tab_embed_bwd(const float* g, const float* x, const int* cat_offsets, c
 int stil_tokmean_fwd(const float* x, float* y, int B, int T, int D, void* stream);
 int stil_tokmean_bwd(const float* g, float* dx, int B, int T, int D, void* stream);
 
+/* ---- SAINT tabular encoder (config_dvm_STiL_SAINT): STiLModel_SAINT_backbone.py:159-184, SAINT/model_util.py:43-59,79-122
+ * token j < ncat+1 of out [B,nfeats,d]: embeds[(j ? int(x[b,cat_cols[j-1]]) : 0) + cat_offsets[j]] + pos_enc[j];
+ * tokens tok0+j: the per-continuous-column simple_MLP(1 -> hid -> d), all columns in ONE launch (the reference loops in
+ * Python); param_ptrs / grad_ptrs are device arrays of ncon*4 pointers {w1[hid], b1[hid], W2[d,hid], b2[d]}. */
+int stil_saint_embed_fwd(const float* x, const int* cat_cols, const int* cat_offsets, const float* embeds,
+                         const float* pos_enc, float* out, int B, int ncols, int ncat, int nfeats, int d, void* stream);
+int stil_saint_embed_bwd(const float* g, const float* x, const int* cat_cols, const int* cat_offsets,
+                         const int* rowcol, int n_emb_rows, float* d_embeds, float* d_pos, int B, int ncols,
+                         int ncat, int nfeats, int d, int accumulate, void* stream);
+int stil_colmlp_fwd(const float* x, const int* con_cols, const float* const* param_ptrs, float* out, int B,
+                    int ncols, int ncon, int nfeats, int tok0, int hid, int d, void* stream);
+int stil_colmlp_bwd(const float* g, const float* x, const int* con_cols, const float* const* param_ptrs,
+                    float* const* grad_ptrs, int B, int ncols, int ncon, int nfeats, int tok0, int hid, int d,
+                    int accumulate, void* stream);
+/* GEGLU: out[r, :H] = h[r, :H] * gelu(h[r, H:]);  row softmax (inter-sample attention over the batch) */
+int stil_geglu_fwd(const float* h, float* out, long rows, int H, void* stream);
+int stil_geglu_bwd(const float* g, const float* h, float* dh, long rows, int H, void* stream);
+int stil_row_softmax_fwd(const float* z, float* p, int rows, int C, void* stream);
+int stil_row_softmax_bwd(const float* g, const float* p, float* dz, int rows, int C, void* stream);
+
 /* ---- loss tail: STiLModel.py:259-303,339,374-381; utils/clip_loss.py; utils/prototype_loss.py; club.py */
 int stil_ce_hard(const float* logits, int ld, const long long* labels, float* row_loss, float* dlogits,
                  int ldd, int rows, int K, float inv_rows, void* stream);

@@ -132,12 +132,16 @@ class MaskProvider:
     ORDER = ["attn_i", "attn_t", "attn_c", "proj_i", "proj_t", "proj_c", "dp1_i", "dp1_t", "dp1_c",
              "fc1_i", "fc2_i", "dp2_i", "fc1_t", "fc2_t", "dp2_t", "fc1_c", "fc2_c", "dp2_c"]
 
-    def __init__(self, masks):
-        self.masks = masks
+    def __init__(self, masks, saint=None):
+        self.masks = dict(masks)
+        self.order = list(self.ORDER)
+        if saint is not None:  # the SAINT encoder's two FF dropouts are called before the MI layer's
+            self.masks.update(saint)
+            self.order = ["ff_col", "ff_row"] + self.order
         self.i = 0
 
     def next(self, shape):
-        name = self.ORDER[self.i % len(self.ORDER)]
+        name = self.order[self.i % len(self.order)]
         self.i += 1
         m = self.masks[name]
         assert tuple(m.shape) == tuple(shape), (name, m.shape, shape)
@@ -215,6 +219,8 @@ CASES = {
     "cardiac_r50": (dict(img_size=64, num_classes=2, target="CAD", field_lengths=[4] * 6 + [1] * 9, batch_size=16,
                          th1=0.62, start_epoch=1, rate_pseudo=0.95, ema_momentum=0.4, beta=1.0, gamma=1.0, lr_eval=1e-3),
                     16, 5, False, True),
+    "dvm_saint": (dict(img_size=64, num_classes=7, field_lengths=[3, 4, 1, 5, 1, 1, 2], batch_size=16, th1=0.5, start_epoch=1,
+                       tabular_encoder="saint"), 16, 5, True, True),
     "dvm_r18_noeman": (dict(model="resnet18", embedding_dim=512, img_size=64, num_classes=5,
                             field_lengths=[3, 4] + [1] * 3, batch_size=8, th1=0.25, start_epoch=1, eman=False),
                        8, 3, False, True),
@@ -226,7 +232,9 @@ TENSORS = ["y_hat_m", "y_hat_i", "y_hat_t", "x_si_enhance", "x_si", "x_ai", "x_s
            "feat_m", "feat_i", "feat_t", "y_hat_m_e", "y_hat_i_e", "y_hat_t_e", "feat_m_e", "pseudo_label_orig",
            "pseudo_label", "prediction", "case1", "case2_i", "case2_t", "case3", "mask1", "mask_random",
            "class_sum", "class_count"]
-FULL_GRADS = ["model.classifier_multimodal.weight", "model.reduce.bias", "model.encoder_tabular.cls_token",
+FULL_GRADS = ["model.encoder_tabular.simple_MLP.1.layers.0.weight", "model.encoder_tabular.embeds.weight",
+              "model.encoder_tabular.pos_encodings.weight", "model.encoder_tabular.transformer.layers.0.2.fn.fn.to_out.bias",
+              "model.encoder_tabular.transformer.layers.0.1.fn.fn.net.3.weight", "model.classifier_multimodal.weight", "model.reduce.bias", "model.encoder_tabular.cls_token",
               "model.encoder_tabular.con_proj.weight", "model.encoder_imaging.bn1.weight",
               "model.encoder_imaging.layer1.0.bn3.bias", "projector_imaging.bias", "CLUB_imaging.p_mu.2.bias",
               "model.transformer.0.attn.qkv.bias", "model.encoder_tabular.norm.weight",
@@ -248,19 +256,29 @@ def build_case(name):
         Ni = (hp.img_size // 32) ** 2
         Nt = len(hp.field_lengths)
         mi_masks = {0: make_mi_masks(B, Ni, Nt, hp.multimodal_embedding_dim, 4, hp.mi_drop, seed=5)}
+        if hp.tabular_encoder == "saint":  # FF dropout p = 0.8 of the SAINT col / row feed-forwards (GEGLU output)
+            g2 = torch.Generator().manual_seed(6)
+            nf = Nt + 1
+            mi_masks["saint"] = {"ff_col": torch.rand(B, nf, 4 * O.SAINT_DIM, generator=g2) >= hp.saint_ff_drop,
+                                 "ff_row": torch.rand(1, B, 4 * O.SAINT_DIM * nf, generator=g2) >= hp.saint_ff_drop}
     if prefill:
         sd = craft_heads(sd, batch, hp, epoch, mask_random)
     return hp, sd, batch, epoch, mask_random, mi_masks
 
 
 def run_reference(hp, sd, batch, epoch, mask_random, mi_masks):
-    from models.Disentangle.STiLModel import STiLModel
     import models.Disentangle.utils.disentangle_transformer as DT
+    if hp.tabular_encoder == "saint":
+        from models.Disentangle.STiLModel_SAINT import SemiDisCoPseudoSmooth as STiLModel
+    else:
+        from models.Disentangle.STiLModel import STiLModel
 
     with tempfile.TemporaryDirectory() as td:
         fl = os.path.join(td, "fl.pt")
         torch.save(list(hp.field_lengths), fl)
-        model = STiLModel(ref_hparams(hp, fl))
+        rh = ref_hparams(hp, fl)
+        rh["checkpoint_SAINT"] = None
+        model = STiLModel(rh)
     ref_keys = list(model.state_dict().keys())
     missing = set(ref_keys) ^ set(sd.keys())
     assert not missing, f"state_dict key mismatch: {sorted(missing)[:10]}"
@@ -269,7 +287,7 @@ def run_reference(hp, sd, batch, epoch, mask_random, mi_masks):
     model.train()
     model.current_epoch = epoch
 
-    provider = MaskProvider(mi_masks[0]) if mi_masks else None
+    provider = MaskProvider(mi_masks[0], mi_masks.get("saint")) if mi_masks else None
     orig_dropout_fwd, orig_drop_path, orig_rand_like = nn.Dropout.forward, DT.drop_path, torch.rand_like
 
     def dropout_fwd(self, x):

@@ -54,6 +54,8 @@ def default_hparams(**over) -> SimpleNamespace:
         use_ema=True, eman=True, ema_momentum=0.996, DA=False,
         repeat_ratio=1.0, batch_size=32, lr_eval=1e-4, weight_decay_eval=0.0,
         mi_drop=0.1,  # attn_drop = proj_drop = drop_path of MITransformerLayer (backbone.py:60)
+        tabular_encoder="transformer",  # "saint" = STiLModel_SAINT.py / STiLModel_SAINT_backbone.py variant
+        saint_ff_drop=0.8,  # ff_dropout of the SAINT RowColTransformer (STiLModel_SAINT_backbone.py:120-122)
         scheduler="anneal", warmup_epochs=10, max_epochs=500,
     )
     hp.update(over)
@@ -98,6 +100,117 @@ def resnet_spec(model: str):
     return kind, layers
 
 
+SAINT_DIM = 32      # STiLModel_SAINT_backbone.py:110-121: colrow attention -> depth 1, 4 heads, embedding 32
+SAINT_HEADS = 4
+
+
+def init_saint_state(hp, gen) -> Dict[str, Tensor]:
+    """SAINT(...) state_dict in the reference's key order (SAINT/Tabular_Encoder.py:24-146, model_util.py:90-110).
+    Only embeds, pos_encodings, simple_MLP and transformer.layers are used by STiL's forward; the rest is carried
+    (EMA'd, never trained) exactly like the reference does."""
+    cat, con = split_field_lengths(hp.field_lengths)
+    ncat, ncon, d = len(cat), len(con), SAINT_DIM
+    nfeats = ncat + ncon + 1
+    total_tokens = sum(cat) + 1
+    sd: Dict[str, Tensor] = {}
+    sd["categories_offset"] = torch.tensor([0, 1] + cat).cumsum(0)[:-1]
+    sd["cat_mask_offset"] = torch.tensor([0, 2] + [2] * ncat).cumsum(0)[:-1]
+    sd["con_mask_offset"] = F.pad(torch.full((ncon,), 2.0).to(torch.int8), (1, 0), value=0).cumsum(0)[:-1]
+    sd["norm.weight"] = torch.ones(ncon); sd["norm.bias"] = torch.zeros(ncon)
+
+    def emb(name, n, dim):
+        sd[name + ".weight"] = torch.randn(n, dim, generator=gen)
+
+    def smlp(name, dims):
+        _linear_init(sd, name + ".layers.0", dims[1], dims[0], gen)
+        _linear_init(sd, name + ".layers.2", dims[2], dims[1], gen)
+
+    for i in range(ncon):
+        smlp(f"simple_MLP.{i}", [1, 100, d])
+    emb("transformer.embeds", total_tokens, d)
+    for li, (dim, dh) in enumerate(((d, 16), (d, None), (d * nfeats, 64), (d * nfeats, None))):
+        q = f"transformer.layers.0.{li}."
+        sd[q + "norm.weight"] = torch.ones(dim); sd[q + "norm.bias"] = torch.zeros(dim)
+        if dh is not None:
+            _linear_init(sd, q + "fn.fn.to_qkv", 3 * SAINT_HEADS * dh, dim, gen, bias=False)
+            _linear_init(sd, q + "fn.fn.to_out", dim, SAINT_HEADS * dh, gen)
+        else:
+            _linear_init(sd, q + "fn.fn.net.0", dim * 8, dim, gen)
+            _linear_init(sd, q + "fn.fn.net.3", dim, dim * 4, gen)
+    emb("transformer.mask_embed", nfeats, d)
+    input_size = d * ncat + d * ncon
+    l = input_size // 8
+    dims = [input_size, l * 4, l * 2, 1]
+    for i in range(3):
+        _linear_init(sd, f"mlp.mlp.{i}", dims[i + 1], dims[i], gen)
+    emb("embeds", total_tokens, d)
+    emb("mask_embeds_cat", ncat * 2 + 2, d)
+    emb("mask_embeds_cont", ncon * 2, d)
+    emb("single_mask", 2, d)
+    emb("pos_encodings", ncat + ncon, d)
+    for i in range(ncat):
+        smlp(f"mlp1.layers.{i}", [d, 5 * d, cat[i]])
+    for i in range(ncon):
+        smlp(f"mlp2.layers.{i}", [d, 5 * d, 1])
+    smlp("mlpfory", [d, 1000, hp.num_classes])
+    smlp("pt_mlp", [d * nfeats, 6 * d * nfeats // 5, d * nfeats // 2])
+    smlp("pt_mlp2", [d * nfeats, 6 * d * nfeats // 5, d * nfeats // 2])
+    return sd
+
+
+def _saint_attention(x, wqkv, wo, bo, heads):
+    """SAINT/model_util.py:79-87 (the constructed dropout is never applied)."""
+    b, n, _ = x.shape
+    q, k, v = F.linear(x, wqkv).chunk(3, dim=-1)
+    dh = q.shape[-1] // heads
+    q, k, v = (t.reshape(b, n, heads, dh).permute(0, 2, 1, 3) for t in (q, k, v))
+    attn = ((q @ k.transpose(-2, -1)) * dh ** -0.5).softmax(dim=-1)
+    out = (attn @ v).permute(0, 2, 1, 3).reshape(b, n, heads * dh)
+    return F.linear(out, wo, bo)
+
+
+def saint_tabular_forward(sd, pb, x_t, hp, masks=None):
+    """DisCoAttentionBackbone.forward_tabular (STiLModel_SAINT_backbone.py:159-184) + RowColTransformer.forward
+    'colrow' (SAINT/model_util.py:111-122).  pb = backbone prefix ("model." / "ema.").
+    masks (train-mode FF dropout p = 0.8, injected): {"ff_col": [B,nfeats,4*d], "ff_row": [1,B,4*d*nfeats]} or None."""
+    p = pb + "encoder_tabular."
+    cat_cols = [i for i, c in enumerate(hp.field_lengths) if int(c) != 1]
+    con_cols = [i for i, c in enumerate(hp.field_lengths) if int(c) == 1]
+    B = x_t.shape[0]
+    cls = sd[pb + "cls_token"].expand(B, -1)
+    x_categ = torch.cat((cls, x_t[:, cat_cols]), dim=1).long() + sd[p + "categories_offset"]
+    x_categ_enc = F.embedding(x_categ, sd[p + "embeds.weight"])
+    conts = []
+    for j, col in enumerate(con_cols):
+        h = F.relu(F.linear(x_t[:, col].reshape(B, 1), sd[p + f"simple_MLP.{j}.layers.0.weight"], sd[p + f"simple_MLP.{j}.layers.0.bias"]))
+        conts.append(F.linear(h, sd[p + f"simple_MLP.{j}.layers.2.weight"], sd[p + f"simple_MLP.{j}.layers.2.bias"]))
+    x_categ_enc = x_categ_enc + sd[p + "pos_encodings.weight"][: x_categ.shape[1]].unsqueeze(0)
+    x = torch.cat([x_categ_enc] + ([torch.stack(conts, dim=1)] if conts else []), dim=1)  # [B, nfeats, d]
+    n = x.shape[1]
+    q = p + "transformer.layers.0."
+    pdrop = hp.saint_ff_drop
+
+    def prenorm_res(x, li, fn):  # PreNorm(dim, Residual(fn)): fn(norm(x)) + norm(x)
+        xn = F.layer_norm(x, (x.shape[-1],), sd[q + f"{li}.norm.weight"], sd[q + f"{li}.norm.bias"], eps=1e-5)
+        return fn(xn) + xn
+
+    def ff(li, mask):
+        def f(xn):
+            h = F.linear(xn, sd[q + f"{li}.fn.fn.net.0.weight"], sd[q + f"{li}.fn.fn.net.0.bias"])
+            a, gates = h.chunk(2, dim=-1)
+            h = _drop(a * F.gelu(gates), mask, pdrop)
+            return F.linear(h, sd[q + f"{li}.fn.fn.net.3.weight"], sd[q + f"{li}.fn.fn.net.3.bias"])
+        return f
+
+    mk = (lambda k: None) if masks is None else (lambda k: masks.get(k))
+    x = prenorm_res(x, 0, lambda xn: _saint_attention(xn, sd[q + "0.fn.fn.to_qkv.weight"], sd[q + "0.fn.fn.to_out.weight"], sd[q + "0.fn.fn.to_out.bias"], SAINT_HEADS))
+    x = prenorm_res(x, 1, ff(1, mk("ff_col")))
+    x = x.reshape(1, B, n * SAINT_DIM)  # row (inter-sample) attention over the batch
+    x = prenorm_res(x, 2, lambda xn: _saint_attention(xn, sd[q + "2.fn.fn.to_qkv.weight"], sd[q + "2.fn.fn.to_out.weight"], sd[q + "2.fn.fn.to_out.bias"], SAINT_HEADS))
+    x = prenorm_res(x, 3, ff(3, mk("ff_row")))
+    return x.reshape(B, n, SAINT_DIM)
+
+
 def init_backbone_state(hp, gen) -> Dict[str, Tensor]:
     """DisCoAttentionBackbone parameters + buffers (STiLModel_backbone.py:45-68)."""
     sd: Dict[str, Tensor] = {}
@@ -122,28 +235,34 @@ def init_backbone_state(hp, gen) -> Dict[str, Tensor]:
                 _conv_init(sd, q + "downsample.0", planes * exp, inplanes, 1, gen)
                 _bn_init(sd, q + "downsample.1", planes * exp)
             inplanes = planes * exp
-    # tabular encoder (models/Transformer.py:193-238)
+    # tabular encoder
     cat, con = split_field_lengths(hp.field_lengths)
-    D = hp.tabular_embedding_dim
     p = "encoder_tabular."
-    sd[p + "cls_token"] = torch.nn.init.trunc_normal_(torch.zeros(1, 1, D), std=0.02, generator=gen)
-    sd[p + "mask_special_token"] = torch.nn.init.trunc_normal_(torch.zeros(1, 1, D), std=0.02, generator=gen)
-    sd[p + "cat_embedding.weight"] = torch.randn(max(sum(cat), 1) if cat else 0, D, generator=gen) * 0.02
-    sd[p + "con_proj.weight"] = torch.randn(D, 1, generator=gen) * 0.02
-    sd[p + "con_proj.bias"] = torch.zeros(D)
-    sd[p + "column_embedding.weight"] = torch.randn(len(cat) + len(con) + 1, D, generator=gen) * 0.02
-    sd[p + "norm.weight"] = torch.ones(D); sd[p + "norm.bias"] = torch.zeros(D)
-    for i in range(hp.tabular_transformer_num_layers):
-        q = f"{p}transformer_blocks.{i}."
-        sd[q + "norm1.weight"] = torch.ones(D); sd[q + "norm1.bias"] = torch.zeros(D)
-        sd[q + "attn.qkv.weight"] = torch.randn(3 * D, D, generator=gen) * 0.02
-        sd[q + "attn.proj.weight"] = torch.randn(D, D, generator=gen) * 0.02
-        sd[q + "attn.proj.bias"] = torch.zeros(D)
-        sd[q + "norm2.weight"] = torch.ones(D); sd[q + "norm2.bias"] = torch.zeros(D)
-        sd[q + "mlp.fc1.weight"] = torch.randn(4 * D, D, generator=gen) * 0.02
-        sd[q + "mlp.fc1.bias"] = torch.zeros(4 * D)
-        sd[q + "mlp.fc2.weight"] = torch.randn(D, 4 * D, generator=gen) * 0.02
-        sd[q + "mlp.fc2.bias"] = torch.zeros(D)
+    if getattr(hp, "tabular_encoder", "transformer") == "saint":
+        # backbone-level nn.Parameter cls_token (STiLModel_SAINT_backbone.py:138) precedes the submodules in state_dict order
+        sd = {"cls_token": torch.zeros(1, 1), **sd}
+        sd.update({p + k: v for k, v in init_saint_state(hp, gen).items()})
+        D = SAINT_DIM
+    else:  # models/Transformer.py:193-238
+        D = hp.tabular_embedding_dim
+        sd[p + "cls_token"] = torch.nn.init.trunc_normal_(torch.zeros(1, 1, D), std=0.02, generator=gen)
+        sd[p + "mask_special_token"] = torch.nn.init.trunc_normal_(torch.zeros(1, 1, D), std=0.02, generator=gen)
+        sd[p + "cat_embedding.weight"] = torch.randn(max(sum(cat), 1) if cat else 0, D, generator=gen) * 0.02
+        sd[p + "con_proj.weight"] = torch.randn(D, 1, generator=gen) * 0.02
+        sd[p + "con_proj.bias"] = torch.zeros(D)
+        sd[p + "column_embedding.weight"] = torch.randn(len(cat) + len(con) + 1, D, generator=gen) * 0.02
+        sd[p + "norm.weight"] = torch.ones(D); sd[p + "norm.bias"] = torch.zeros(D)
+        for i in range(hp.tabular_transformer_num_layers):
+            q = f"{p}transformer_blocks.{i}."
+            sd[q + "norm1.weight"] = torch.ones(D); sd[q + "norm1.bias"] = torch.zeros(D)
+            sd[q + "attn.qkv.weight"] = torch.randn(3 * D, D, generator=gen) * 0.02
+            sd[q + "attn.proj.weight"] = torch.randn(D, D, generator=gen) * 0.02
+            sd[q + "attn.proj.bias"] = torch.zeros(D)
+            sd[q + "norm2.weight"] = torch.ones(D); sd[q + "norm2.bias"] = torch.zeros(D)
+            sd[q + "mlp.fc1.weight"] = torch.randn(4 * D, D, generator=gen) * 0.02
+            sd[q + "mlp.fc1.bias"] = torch.zeros(4 * D)
+            sd[q + "mlp.fc2.weight"] = torch.randn(D, 4 * D, generator=gen) * 0.02
+            sd[q + "mlp.fc2.bias"] = torch.zeros(D)
     C = hp.multimodal_embedding_dim
     for nm, din, dh in (("projection_si", hp.embedding_dim, C), ("projection_ai", hp.embedding_dim, C),
                         ("projection_st", D, D), ("projection_at", D, D)):
@@ -201,6 +320,8 @@ def trainable_keys(sd: Dict[str, Tensor]) -> List[str]:
         if k.startswith("ema.") or k.startswith("prototypes"):
             continue
         if k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"):
+            continue
+        if not v.is_floating_point():  # SAINT's int64 *_offset buffers
             continue
         out.append(k)
     return out
@@ -358,7 +479,11 @@ def backbone_forward_all(sd, p, x_img, x_tab, hp, train: bool, masks=None):
     f = resnet_forward(sd, p + "encoder_imaging.", x_img, hp.model, train)  # [B,C,H,W]
     B, Cc, Hh, Ww = f.shape
     x_i = f.reshape(B, Cc, Hh * Ww).permute(0, 2, 1)
-    x_t = tabular_forward(sd, p + "encoder_tabular.", x_tab, hp)
+    if getattr(hp, "tabular_encoder", "transformer") == "saint":
+        sm = None if (masks is None or not train) else masks.get("saint")
+        x_t = saint_tabular_forward(sd, p, x_tab, hp, sm)
+    else:
+        x_t = tabular_forward(sd, p + "encoder_tabular.", x_tab, hp)
     x_si = _mlp2(sd, p + "projection_si.", x_i)
     x_ai = _mlp2(sd, p + "projection_ai.", x_i.mean(dim=1))
     x_st = _mlp2(sd, p + "projection_st.", x_t[:, 1:, :])
@@ -435,7 +560,7 @@ def ema_update(sd, m: float, eman: bool = True):
             is_buf = k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked")
             if is_buf and not eman:
                 continue
-            if k.endswith("num_batches_tracked"):
+            if k.endswith("num_batches_tracked") or "offset" in k:  # STiLModel.py:162 / STiLModel_SAINT.py:161
                 sd[ke].copy_(v)
             else:
                 sd[ke].mul_(m).add_((1.0 - m) * v.detach())
@@ -589,6 +714,16 @@ def full_step(sd, opt, step_idx, batch, hp, current_epoch, mask_random=None, mi_
 # --------------------------------------------------------------------------
 # synthetic batch in the reference's batch layout
 # --------------------------------------------------------------------------
+def field_order_permutation(field_lengths):
+    """Index list that scatters [categorical..., continuous...] generated columns to their positions in field order."""
+    cat_pos = [i for i, c in enumerate(field_lengths) if int(c) != 1]
+    con_pos = [i for i, c in enumerate(field_lengths) if int(c) == 1]
+    perm = [0] * len(field_lengths)
+    for j, pos in enumerate(cat_pos + con_pos):
+        perm[pos] = j
+    return perm
+
+
 def synthetic_batch(hp, B: int, seed: int = 2022, img_size: Optional[int] = None):
     g = torch.Generator().manual_seed(seed)
     P = img_size or hp.img_size
@@ -598,6 +733,7 @@ def synthetic_batch(hp, B: int, seed: int = 2022, img_size: Optional[int] = None
     cols = [torch.randint(0, c, (B, 1), generator=g).float() for c in cat]
     cols.append(torch.randn(B, len(con), generator=g))
     tab = torch.cat(cols, dim=1)
+    tab = tab[:, field_order_permutation(hp.field_lengths)]  # identity for categorical-first column orders
     y = torch.randint(0, hp.num_classes, (B,), generator=g)
 
     def part(sl, lab):

@@ -5,6 +5,16 @@ Importing the package does not need a GPU; running any operator does (there is n
 from ._lib import lib, build, LIB_PATH  # noqa: F401
 from .stil_model import STiLModel  # noqa: F401
 
-# trainers/evaluate.py:146 imports STiLModel from STiLModel_SAINT although the class there is called
-# SemiDisCoPseudoSmooth; both names are exported once the SAINT variant lands.
-__all__ = ["STiLModel", "lib", "build", "LIB_PATH"]
+
+
+class SemiDisCoPseudoSmooth(STiLModel):
+    """models/Disentangle/STiLModel_SAINT.py:29 -- the SAINT-encoder variant.  trainers/evaluate.py:146 imports it as
+    `STiLModel` from that module although the class is called SemiDisCoPseudoSmooth; both spellings work here."""
+
+    def __init__(self, hparams):
+        hp = dict(hparams) if isinstance(hparams, dict) else dict(getattr(hparams, "__dict__", None) or {k: hparams[k] for k in hparams.keys()})
+        hp["tabular_encoder"] = "saint"
+        super().__init__(hp)
+
+
+__all__ = ["STiLModel", "SemiDisCoPseudoSmooth", "lib", "build", "LIB_PATH"]

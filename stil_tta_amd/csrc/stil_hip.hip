@@ -22,4 +22,5 @@ extern "C" int stil_device_count(void) {
 #include "bn.hip"
 #include "transformer.hip"
 #include "loss.hip"
+#include "saint.hip"
 #include "optim.hip"

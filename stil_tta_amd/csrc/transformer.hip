@@ -461,6 +461,12 @@ extern "C" int stil_layernorm_bwd(const float* g, const float* x, const float* g
                                   float* workspace, size_t workspace_bytes, void* stream) {
   STIL_REQUIRE(g && x && gamma && mean_rstd && dx && dgamma && dbeta && workspace, "stil_layernorm_bwd: null pointer");
   STIL_REQUIRE(D <= 4096, "stil_layernorm_bwd: D=%d > 4096", D);
+  static bool attr_set = false;
+  if (!attr_set) {  // 8*D floats of LDS: > 64 KiB for D > 2048 (SAINT's row LayerNorm has D = 32 * nfeats = 2080)
+    hipError_t e = hipFuncSetAttribute((const void*)layernorm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+    if (e != hipSuccess) { stil_set_error("layernorm_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return STIL_EHIP; }
+    attr_set = true;
+  }
   int nb = ln_blocks(rows);
   STIL_REQUIRE(workspace_bytes >= (size_t)nb * 2 * D * sizeof(float), "stil_layernorm_bwd: workspace too small");
   int rpb = cdiv(rows, nb);

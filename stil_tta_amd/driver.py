@@ -97,6 +97,12 @@ def synthetic_batch(field_lengths, num_classes: int, B: int, img_size: int, seed
     cols = [torch.randint(0, c, (B, 1), generator=g).float() for c in cat]
     cols.append(torch.randn(B, ncon, generator=g))
     tab = torch.cat(cols, dim=1)
+    cat_pos = [i for i, c in enumerate(field_lengths) if int(c) != 1]
+    con_pos = [i for i, c in enumerate(field_lengths) if int(c) == 1]
+    perm = [0] * len(field_lengths)
+    for j, pos in enumerate(cat_pos + con_pos):
+        perm[pos] = j
+    tab = tab[:, perm]  # identity for categorical-first column orders (the base model requires that order)
     y = torch.randint(0, num_classes, (B,), generator=g)
     img, tab, y = img.to(device), tab.to(device), y.to(device)
 

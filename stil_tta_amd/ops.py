@@ -735,3 +735,114 @@ def cgpl_pgls(zm, zi, zt, feat_u, prototypes, mask_random, rate_pseudo, T, th, u
     lib().cgpl_pgls(_p(zm), _p(zi), _p(zt), K, _p(feat_u), _p(prototypes), _p(mask_random), _p(pl), _p(po), _p(pred),
                     _p(flags), _p(hard), _p(w3), Bu, K, Dp, rate_pseudo, T, th, 1 if use_pseudo else 0, _stream())
     return pl, po, pred, flags, hard, w3
+
+
+# ------------------------------------------------------------------------------------------ SAINT tabular encoder
+class SaintEmbedColMlpFn(torch.autograd.Function):
+    """Token buffer [B, nfeats, d] of DisCoAttentionBackbone.forward_tabular (STiLModel_SAINT_backbone.py:159-178):
+    categorical tokens = embeds[code + offset] + pos_encodings, continuous tokens = per-column simple_MLP(1->100->d)."""
+
+    @staticmethod
+    def forward(ctx, x, embeds, pos, meta, *mlp_params):
+        _chk(x, embeds, pos)
+        B, ncols = x.shape
+        d = embeds.shape[1]
+        ncat, ncon, hid = meta["ncat"], meta["ncon"], meta["hid"]
+        nfeats = ncat + ncon + 1
+        out = torch.empty((B, nfeats, d), dtype=torch.float32, device=x.device)
+        lib().saint_embed_fwd(_p(x), _p(meta["cat_cols"]), _p(meta["offs"]), _p(embeds), _p(pos), _p(out), B, ncols, ncat,
+                              nfeats, d, _stream())
+        if ncon:
+            ptrs = torch.tensor([t.data_ptr() for t in mlp_params], dtype=torch.int64, device=x.device)
+            lib().colmlp_fwd(_p(x), _p(meta["con_cols"]), _p(ptrs), _p(out), B, ncols, ncon, nfeats, ncat + 1, hid, d, _stream())
+            ctx.ptrs = ptrs
+        ctx.save_for_backward(x, embeds, pos, *mlp_params)
+        ctx.meta = meta
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, embeds, pos, *mlp_params = ctx.saved_tensors
+        meta = ctx.meta
+        B, ncols = x.shape
+        d = embeds.shape[1]
+        ncat, ncon, hid = meta["ncat"], meta["ncon"], meta["hid"]
+        nfeats = ncat + ncon + 1
+        g = g.contiguous()
+        params = [embeds, pos] + list(mlp_params)
+        use_slab = getattr(embeds, "_gslot", None) is not None
+        outs = [p_._gslot if use_slab else torch.zeros_like(p_) for p_ in params]
+        acc = 1 if use_slab else 0
+        lib().saint_embed_bwd(_p(g), _p(x), _p(meta["cat_cols"]), _p(meta["offs"]), _p(meta["rowcol"]), embeds.shape[0],
+                              _p(outs[0]), _p(outs[1]), B, ncols, ncat, nfeats, d, acc, _stream())
+        if ncon:
+            gptrs = torch.tensor([t.data_ptr() for t in outs[2:]], dtype=torch.int64, device=x.device)
+            lib().colmlp_bwd(_p(g), _p(x), _p(meta["con_cols"]), _p(ctx.ptrs), _p(gptrs), B, ncols, ncon, nfeats, ncat + 1, hid,
+                             d, acc, _stream())
+        if use_slab:
+            for p_ in params:
+                p_._stil_touched = True
+            return (None,) * (4 + len(mlp_params))
+        return (None, outs[0], outs[1], None, *outs[2:])
+
+
+class GegluFn(torch.autograd.Function):
+    """GEGLU (SAINT/model_util.py:43-46): x, gates = h.chunk(2, -1); x * gelu(gates)."""
+
+    @staticmethod
+    def forward(ctx, h):
+        _chk(h)
+        H = h.shape[-1] // 2
+        rows = h.numel() // (2 * H)
+        out = torch.empty((*h.shape[:-1], H), dtype=torch.float32, device=h.device)
+        lib().geglu_fwd(_p(h), _p(out), rows, H, _stream())
+        ctx.save_for_backward(h)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (h,) = ctx.saved_tensors
+        H = h.shape[-1] // 2
+        g = g.contiguous()
+        dh = torch.empty_like(h)
+        lib().geglu_bwd(_p(g), _p(h), _p(dh), h.numel() // (2 * H), H, _stream())
+        return dh
+
+
+class RowSoftmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z):
+        _chk(z)
+        R, C = z.shape
+        p = torch.empty_like(z)
+        lib().row_softmax_fwd(_p(z), _p(p), R, C, _stream())
+        ctx.save_for_backward(p)
+        return p
+
+    @staticmethod
+    def backward(ctx, g):
+        (p,) = ctx.saved_tensors
+        g = g.contiguous()
+        dz = torch.empty_like(p)
+        lib().row_softmax_bwd(_p(g), _p(p), _p(dz), p.shape[0], p.shape[1], _stream())
+        return dz
+
+
+class MatmulNNFn(torch.autograd.Function):
+    """C = A @ B (A [M,K], B [K,N]) -- P @ V of the inter-sample attention."""
+
+    @staticmethod
+    def forward(ctx, A, B):
+        _chk(A, B)
+        ctx.save_for_backward(A, B)
+        return gemm_nt(A, transpose(B), A.shape[0], B.shape[1], A.shape[1])
+
+    @staticmethod
+    def backward(ctx, gC):
+        A, B = ctx.saved_tensors
+        gC = gC.contiguous()
+        M, K = A.shape
+        N = B.shape[1]
+        dA = gemm_nt(gC, B, M, K, N)                         # gC [M,N] . B^T  (B is [K,N] = "W[K,N]")
+        dB = gemm_nt(transpose(A), transpose(gC), K, N, M)   # A^T [K,M] . gC [M,N]
+        return dA, dB

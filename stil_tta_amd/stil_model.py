@@ -40,6 +40,7 @@ _DEFAULTS = dict(
     batch_size=512, lr_eval=1e-4, weight_decay_eval=0.0, scheduler="anneal", warmup_epochs=10, max_epochs=500,
     checkpoint=None, pretrained_model="TIP", finetune_strategy="trainable", pretrain=False, logdir=None,
     mi_dropout=True, seed=2022,
+    tabular_encoder="transformer",  # "saint": the STiLModel_SAINT.py variant (also selected by algorithm_name == "STiL_SAINT")
 )
 
 
@@ -100,7 +101,14 @@ class STiLModel(_Base):
             fl = torch.load(hp.field_lengths_tabular)  # STiLModel_backbone.py:97
         self.field_lengths = [int(v) for v in fl]
         C, Dp = hp.multimodal_embedding_dim, hp.projection_dim
-        self.model = DisCoAttentionBackbone(hp, self.field_lengths)
+        if str(getattr(hp, "algorithm_name", "")).upper().endswith("SAINT"):
+            hp.tabular_encoder = "saint"
+        if hp.tabular_encoder == "saint":
+            from .saint import SaintBackbone
+            self._backbone_cls = SaintBackbone
+        else:
+            self._backbone_cls = DisCoAttentionBackbone
+        self.model = self._backbone_cls(hp, self.field_lengths)
         self.projector_multimodal = SimCLRProjectionHead(C * 3, C * 3, Dp)
         if hp.target == "dvm":  # STiLModel.py:57-63
             self.projector_imaging = _LinearHead(C, Dp)
@@ -112,7 +120,7 @@ class STiLModel(_Base):
         self.CLUB_tabular = CLUBMean(C, C)
         self.use_ema = bool(hp.use_ema)
         if self.use_ema:
-            self.ema = DisCoAttentionBackbone(hp, self.field_lengths)
+            self.ema = self._backbone_cls(hp, self.field_lengths)
             self.ema.load_state_dict(self.model.state_dict())
             for p in self.ema.parameters():
                 p.requires_grad = False
@@ -167,7 +175,7 @@ class STiLModel(_Base):
             raise RuntimeError("stil_tta_amd: no HIP device visible; the training step has no CPU path")
         device = torch.device(device or "cuda")
         nn.Module.to(self, device)
-        teacher = self.ema if self.use_ema else DisCoAttentionBackbone(self.hp, self.field_lengths).to(device)
+        teacher = self.ema if self.use_ema else self._backbone_cls(self.hp, self.field_lengths).to(device)
         self.flat = FlatState(self.model, teacher, [self.projector_imaging, self.projector_tabular, self.projector_multimodal,
                                                     self.CLUB_imaging, self.CLUB_tabular], device)
         return self
@@ -189,8 +197,15 @@ class STiLModel(_Base):
         return fm, fi, ft
 
     def _mi_masks(self, B, mi_masks):
+        dev = self.prototypes.device
+        saint = self.hp.tabular_encoder == "saint"
         if mi_masks is not None:  # injected (parity tests): oracle layout -> fused layout
-            return {li: fuse_mi_masks(m, self.prototypes.device) for li, m in mi_masks.items()}
+            out = {li: fuse_mi_masks(m, dev) for li, m in mi_masks.items() if li != "saint"}
+            if "saint" in mi_masks:
+                sm = mi_masks["saint"]
+                out["saint"] = {"ff_col": sm["ff_col"].to(device=dev, dtype=torch.uint8).contiguous(),
+                                "ff_row": sm["ff_row"].reshape(B, -1).to(device=dev, dtype=torch.uint8).contiguous()}
+            return out
         if not self.hp.mi_dropout:
             return None
         Ni = (self._img_tokens)
@@ -198,8 +213,13 @@ class STiLModel(_Base):
         C = self.hp.multimodal_embedding_dim
         out = {}
         for li in range(self.hp.multimodal_transformer_num_layers):
-            out[li] = random_mi_masks(B, Ni, Nt, C, 4, 0.1, self.hp.seed, self._rng_offset, self.prototypes.device)
+            out[li] = random_mi_masks(B, Ni, Nt, C, 4, 0.1, self.hp.seed, self._rng_offset, dev)
             self._rng_offset += 4 * B * (1 + Ni + Nt) * (C + 4 * (1 + Ni + Nt))
+        if saint:  # ff_dropout = 0.8 of the SAINT column / row feed-forwards (STiLModel_SAINT_backbone.py:120-122)
+            nf, h4 = Nt + 1, 4 * 32
+            out["saint"] = {"ff_col": ops.rng_mask((B, nf, h4), 0.8, self.hp.seed + 2, self._rng_offset, dev),
+                            "ff_row": ops.rng_mask((B, nf * h4), 0.8, self.hp.seed + 3, self._rng_offset, dev)}
+            self._rng_offset += B * nf * h4
         return out
 
     # ------------------------------------------------------------------ the hot path

@@ -428,3 +428,62 @@ def test_rng_mask_rate_and_determinism(ops):
     c = ops.rng_mask((1 << 20,), 0.1, 7, 1 << 20, "cuda")
     assert torch.equal(a, b) and not torch.equal(a, c)
     assert abs(float(a.float().mean()) - 0.9) < 2e-3
+
+
+def test_saint_pieces(ops):
+    """SAINT embedding + per-column simple_MLP, GEGLU, row softmax, P@V against the oracle's restatement."""
+    from oracle import stil_oracle as O
+    from stil_tta_amd.saint import SaintBackbone
+    g = torch.Generator().manual_seed(3)
+    hp = O.default_hparams(img_size=64, num_classes=5, field_lengths=[3, 4, 1, 5, 1, 1, 2], model="resnet18", embedding_dim=512,
+                           tabular_encoder="saint")
+    B = 12
+    sd = O.init_state(hp, 1)
+    bb = SaintBackbone(hp, hp.field_lengths)
+    bb.load_state_dict({k[6:]: v for k, v in sd.items() if k.startswith("model.")})
+    x = O.synthetic_batch(hp, B)["u"][1][1]
+    x = torch.cat([x, O.synthetic_batch(hp, B, seed=5)["u"][1][1]])[:B]
+    masks = {"ff_col": torch.rand(B, 8, 128, generator=g) >= 0.8, "ff_row": torch.rand(1, B, 128 * 8, generator=g) >= 0.8}
+    keys = [k for k in O.trainable_keys(sd) if k.startswith("model.encoder_tabular.") or k == "model.cls_token"]
+    for k in keys:
+        sd[k].requires_grad_(True)
+    ref = O.saint_tabular_forward(sd, "model.", x, hp, masks)
+    gy = torch.randn(ref.shape, generator=g)
+    gr = torch.autograd.grad(ref, [sd[k] for k in keys], gy, allow_unused=True)
+    bb.cuda()
+    dm = {"ff_col": dev(masks["ff_col"].to(torch.uint8)), "ff_row": dev(masks["ff_row"].reshape(B, -1).to(torch.uint8))}
+    out = bb.forward_tabular(dev(x), dm)
+    close(out, ref, name="saint tokens")
+    out.backward(dev(gy))
+    params = dict(bb.named_parameters())
+    n_checked = 0
+    for k, gref in zip(keys, gr):
+        p = params[k[len("model."):]]
+        if gref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        close(p.grad, gref, tol=5e-5, name="grad " + k)
+        n_checked += 1
+    assert n_checked >= 25
+
+
+def test_geglu_rowsoftmax_matmul_nn(ops):
+    g = torch.Generator().manual_seed(4)
+    h = torch.randn(7, 9, 64, generator=g, requires_grad=True)
+    a, gt = h.chunk(2, -1)
+    y = a * F.gelu(gt)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    hd = dev(h.detach()).requires_grad_()
+    z = ops.GegluFn.apply(hd)
+    z.backward(dev(gy))
+    close(z, y); close(hd.grad, h.grad, name="geglu grad")
+    s = (3 * torch.randn(37, 300, generator=g)).requires_grad_()
+    v = torch.randn(300, 64, generator=g, requires_grad=True)
+    o = s.softmax(-1) @ v
+    go = torch.randn(o.shape, generator=g)
+    o.backward(go)
+    sd_, vd = dev(s.detach()).requires_grad_(), dev(v.detach()).requires_grad_()
+    od = ops.MatmulNNFn.apply(ops.RowSoftmaxFn.apply(sd_), vd)
+    od.backward(dev(go))
+    close(od, o); close(sd_.grad, s.grad, name="dlogits"); close(vd.grad, v.grad, name="dv")
