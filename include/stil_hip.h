@@ -170,8 +170,11 @@ int stil_club_bwd(const float* mu, const float* y, const float* ybar, const floa
  * w3: [3,Bu] row weights of the unlabelled CE terms (multimodal, imaging, tabular). */
 int stil_cgpl_pgls(const float* zm, const float* zi, const float* zt, int ldz, const float* feat_u,
                    const float* prototypes, const unsigned char* mask_random, float* pseudo_label,
-                   float* pseudo_orig, float* prediction, unsigned char* flags, int* hard, float* w3, int Bu,
-                   int K, int Dp, float rate_pseudo, float T, float th, int use_pseudo, void* stream);
+                   float* pseudo_orig, float* prediction, unsigned char* flags, int* hard, float* w3,
+                   const float* pred_in, int Bu, int K, int Dp, float rate_pseudo, float T, float th, int use_pseudo,
+                   void* stream);
+/* distribution alignment (STiLModel.py:171-180): out = (probs / queue_mean) renormalised per row; feed as pred_in above */
+int stil_da_apply(const float* probs, const float* queue_mean, float* out, int rows, int K, void* stream);
 int stil_proto_loss(const float* feat, const float* prototypes, const int* hard, const unsigned char* conf,
                     float* row_loss, float* dfeat_unit, int rows, int K, int Dp, float T, void* stream);
 /* class_sum_cnt: [K, Dp+1] (last column = counts); labelled rows (< B_l) are divided by repeat_ratio */

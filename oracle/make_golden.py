@@ -167,10 +167,14 @@ def make_mi_masks(B, Ni, Nt, C, H, p, seed):
 def randomize_state(sd, seed):
     """Make every tensor non-trivial (BN affine / running stats, biases) so parity is discriminative."""
     g = torch.Generator().manual_seed(seed)
+    if "DA_queue" in sd:  # a partly filled distribution-alignment queue (rows 0..9), pointer at 10
+        K = sd["DA_queue"].shape[1]
+        sd["DA_queue"][:10] = torch.softmax(torch.randn(10, K, generator=g), dim=1)
+        sd["DA_ptr"][0] = 10
     for k, v in sd.items():
         if k.startswith("ema."):
             continue
-        if k.endswith("num_batches_tracked") or k.startswith("prototypes"):
+        if k.endswith("num_batches_tracked") or k.startswith("prototypes") or k.startswith("DA_"):
             continue
         is_bn = (k.replace("weight", "running_var") in sd) and v.ndim == 1 and k.endswith("weight")
         if k.endswith("running_var") or is_bn:
@@ -219,6 +223,8 @@ CASES = {
     "cardiac_r50": (dict(img_size=64, num_classes=2, target="CAD", field_lengths=[4] * 6 + [1] * 9, batch_size=16,
                          th1=0.62, start_epoch=1, rate_pseudo=0.95, ema_momentum=0.4, beta=1.0, gamma=1.0, lr_eval=1e-3),
                     16, 5, False, True),
+    "dvm_r18_DA": (dict(model="resnet18", embedding_dim=512, img_size=64, num_classes=5, field_lengths=[3, 4] + [1] * 3,
+                        batch_size=8, th1=0.25, start_epoch=1, DA=True), 8, 3, False, True),
     "dvm_saint": (dict(img_size=64, num_classes=7, field_lengths=[3, 4, 1, 5, 1, 1, 2], batch_size=16, th1=0.5, start_epoch=1,
                        tabular_encoder="saint"), 16, 5, True, True),
     "dvm_r18_noeman": (dict(model="resnet18", embedding_dim=512, img_size=64, num_classes=5,
@@ -284,6 +290,8 @@ def run_reference(hp, sd, batch, epoch, mask_random, mi_masks):
     assert not missing, f"state_dict key mismatch: {sorted(missing)[:10]}"
     assert ref_keys == list(sd.keys()), "state_dict ORDER differs from the reference"
     model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    if hp.DA and not torch.distributed.is_initialized():  # the reference's DA path calls all_reduce unguarded
+        torch.distributed.init_process_group("gloo", init_method="tcp://127.0.0.1:29731", rank=0, world_size=1)
     model.train()
     model.current_epoch = epoch
 

@@ -291,6 +291,9 @@ def init_state(hp, seed: int = 0) -> Dict[str, Tensor]:
     sd["prototypes"] = torch.zeros(K, Dp)
     sd["prototypes_sum"] = torch.zeros(K, Dp)
     sd["prototypes_count_sum"] = torch.zeros(K, 1)
+    if hp.DA:  # STiLModel.py:100-103
+        sd["DA_queue"] = torch.zeros(256, K)
+        sd["DA_ptr"] = torch.zeros(1, dtype=torch.long)
     bb = init_backbone_state(hp, gen)
     for k, v in bb.items():
         sd["model." + k] = v
@@ -317,7 +320,7 @@ def trainable_keys(sd: Dict[str, Tensor]) -> List[str]:
     """Parameters Adam updates (STiLModel.py:563-570): everything except ema.*, buffers."""
     out = []
     for k, v in sd.items():
-        if k.startswith("ema.") or k.startswith("prototypes"):
+        if k.startswith("ema.") or k.startswith("prototypes") or k.startswith("DA_"):
             continue
         if k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"):
             continue
@@ -610,8 +613,12 @@ def training_step(sd: Dict[str, Tensor], batch, hp, current_epoch: int,
         q0 = (case1[:, None] * ((ym_u + yi_u + yt_u) / 3.0).softmax(1) + case2_i[:, None] * ((ym_u + yi_u) / 2.0).softmax(1)
               + case2_t[:, None] * ((ym_u + yt_u) / 2.0).softmax(1) + case3[:, None] * ym_u.softmax(1))
         prediction = ym_u.softmax(1)
-        if hp.DA:
-            raise NotImplementedError("distribution alignment is restated in the product, not in the oracle (off by default)")
+        if hp.DA:  # distribution_alignment (STiLModel.py:171-180), single process: all_reduce is the identity
+            ptr = int(sd["DA_ptr"])
+            sd["DA_queue"][ptr] = prediction.mean(0)
+            sd["DA_ptr"][0] = (ptr + 1) % sd["DA_queue"].shape[0]
+            prediction = prediction / sd["DA_queue"].mean(0)
+            prediction = prediction / prediction.sum(dim=1, keepdim=True)
 
     ce = F.cross_entropy
     loss_ce = ce(y_m[:B_l], y_l) + ce(y_i[:B_l], y_l) + ce(y_t[:B_l], y_l)

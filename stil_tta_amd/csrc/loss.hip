@@ -188,6 +188,7 @@ struct CgplArgs {
   unsigned char* flags;  // [Bu,4]  case id (1..4), mask1, conf, 0
   int* hard;             // [Bu] argmax of `prediction`
   float* w3;             // [3,Bu] row weights of the three unlabelled CE terms (m, i, t)
+  const float* pred_in;  // optional [Bu,K]: distribution-aligned prediction replacing softmax(zm) (STiLModel.py:276-277)
   int K; float r, T, th; int use_pseudo;
 };
 
@@ -241,7 +242,8 @@ __global__ __launch_bounds__(256) void cgpl_pgls_kernel(CgplArgs p) {
   for (int k = tid; k < K; k += 256) {
     float tp = Ct[k];
     float pl = p.r * A[k] + (1.f - p.r) * tp;
-    float pd = p.r * Bm[k] + (1.f - p.r) * tp;
+    const float pm = p.pred_in ? p.pred_in[(long)u * K + k] : Bm[k];
+    float pd = p.r * pm + (1.f - p.r) * tp;
     p.pseudo_label[(long)u * K + k] = pl;
     if (p.pseudo_orig) p.pseudo_orig[(long)u * K + k] = A[k];
     p.prediction[(long)u * K + k] = p.use_pseudo ? pd : 0.f;
@@ -265,6 +267,17 @@ __global__ __launch_bounds__(256) void cgpl_pgls_kernel(CgplArgs p) {
     p.w3[Bu + u] = (mask1 && (cs == 1 || cs == 3 || (cs == 4 && mr))) ? 1.f : 0.f;
     p.w3[2 * Bu + u] = (mask1 && (cs == 1 || cs == 2 || (cs == 4 && !mr))) ? 1.f : 0.f;
   }
+}
+
+// distribution alignment (STiLModel.py:171-180): out = (p / qmean) renormalised per row
+__global__ __launch_bounds__(256) void da_apply_kernel(const float* __restrict__ p, const float* __restrict__ qmean,
+                                                        float* __restrict__ out, int K) {
+  __shared__ float red[16];
+  const float* pr = p + (long)blockIdx.x * K;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) s += pr[k] / qmean[k];
+  s = block_sum(s, red);
+  for (int k = threadIdx.x; k < K; k += 256) out[(long)blockIdx.x * K + k] = (pr[k] / qmean[k]) / s;
 }
 
 // ---------------------------------------------------------------- PrototypeLoss
@@ -437,16 +450,24 @@ extern "C" int stil_club_bwd(const float* mu, const float* y, const float* ybar,
 
 extern "C" int stil_cgpl_pgls(const float* zm, const float* zi, const float* zt, int ldz, const float* feat_u,
                               const float* prototypes, const unsigned char* mask_random, float* pseudo_label,
-                              float* pseudo_orig, float* prediction, unsigned char* flags, int* hard, float* w3, int Bu,
-                              int K, int Dp, float rate_pseudo, float T, float th, int use_pseudo, void* stream) {
+                              float* pseudo_orig, float* prediction, unsigned char* flags, int* hard, float* w3,
+                              const float* pred_in, int Bu, int K, int Dp, float rate_pseudo, float T, float th,
+                              int use_pseudo, void* stream) {
   STIL_REQUIRE(zm && zi && zt && feat_u && prototypes && mask_random && pseudo_label && prediction && flags && hard && w3,
                "stil_cgpl_pgls: null pointer");
   STIL_REQUIRE(Bu > 0 && K > 0 && (size_t)3 * K * sizeof(float) <= 60 * 1024, "stil_cgpl_pgls: bad shape (Bu=%d K=%d)", Bu, K);
   CgplArgs p;
   p.zm = zm; p.zi = zi; p.zt = zt; p.ldz = ldz; p.feat = feat_u; p.Dp = Dp; p.protos = prototypes;
   p.mask_random = mask_random; p.pseudo_label = pseudo_label; p.pseudo_orig = pseudo_orig; p.prediction = prediction;
-  p.flags = flags; p.hard = hard; p.w3 = w3; p.K = K; p.r = rate_pseudo; p.T = T; p.th = th; p.use_pseudo = use_pseudo;
+  p.flags = flags; p.hard = hard; p.w3 = w3; p.pred_in = pred_in; p.K = K; p.r = rate_pseudo; p.T = T; p.th = th; p.use_pseudo = use_pseudo;
   hipLaunchKernelGGL(cgpl_pgls_kernel, dim3(Bu), dim3(256), (size_t)3 * K * sizeof(float), (hipStream_t)stream, p);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" int stil_da_apply(const float* probs, const float* queue_mean, float* out, int rows, int K, void* stream) {
+  STIL_REQUIRE(probs && queue_mean && out && rows > 0 && K > 0, "stil_da_apply: bad arguments");
+  hipLaunchKernelGGL(da_apply_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, probs, queue_mean, out, K);
   STIL_LAUNCH_CHECK();
   return STIL_OK;
 }

@@ -720,7 +720,7 @@ class ProtoLossFn(torch.autograd.Function):
 
 
 @torch.no_grad()
-def cgpl_pgls(zm, zi, zt, feat_u, prototypes, mask_random, rate_pseudo, T, th, use_pseudo, want_orig=False):
+def cgpl_pgls(zm, zi, zt, feat_u, prototypes, mask_random, rate_pseudo, T, th, use_pseudo, want_orig=False, pred_in=None):
     """CGPL case partition + PGLS smoothing (STiLModel.py:262-299,317-320) in one launch."""
     _chk(zm, zi, zt, feat_u, prototypes, mask_random)
     Bu, K = zm.shape
@@ -733,7 +733,7 @@ def cgpl_pgls(zm, zi, zt, feat_u, prototypes, mask_random, rate_pseudo, T, th, u
     hard = torch.empty((Bu,), dtype=torch.int32, device=dev)
     w3 = torch.empty((3, Bu), dtype=torch.float32, device=dev)
     lib().cgpl_pgls(_p(zm), _p(zi), _p(zt), K, _p(feat_u), _p(prototypes), _p(mask_random), _p(pl), _p(po), _p(pred),
-                    _p(flags), _p(hard), _p(w3), Bu, K, Dp, rate_pseudo, T, th, 1 if use_pseudo else 0, _stream())
+                    _p(flags), _p(hard), _p(w3), _p(pred_in), Bu, K, Dp, rate_pseudo, T, th, 1 if use_pseudo else 0, _stream())
     return pl, po, pred, flags, hard, w3
 
 

@@ -196,6 +196,29 @@ class STiLModel(_Base):
         ft = ops.l2norm(self.projector_tabular.run(feat_t)) if feat_t is not None else None
         return fm, fi, ft
 
+    @torch.no_grad()
+    def distribution_alignment(self, logits_u):
+        """STiLModel.py:171-180 on softmax(y_hat_m_ue): running queue of batch-mean probabilities (256 deep, zero rows
+        included in its mean, as in the reference), probs / queue.mean(0), rows renormalised.  The reference calls
+        all_reduce unguarded (crashes single-process); here the collective runs only when a process group exists."""
+        Bu, K = logits_u.shape
+        dev = logits_u.device
+        probs = torch.empty_like(logits_u)
+        lib().row_softmax_fwd(_p(logits_u), _p(probs), Bu, K, _stream())
+        mean = torch.empty((K,), dtype=torch.float32, device=dev)
+        ops.colsum(probs, mean, Bu, K, scale=1.0 / Bu)
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(mean)
+            mean = mean / dist.get_world_size()
+        ptr = int(self.DA_ptr)  # one host sync per step, as in the reference (STiLModel.py:175); DA is off by default
+        self.DA_queue[ptr].copy_(mean)
+        self.DA_ptr.fill_((ptr + 1) % self.DA_len)
+        qmean = torch.empty((K,), dtype=torch.float32, device=dev)
+        ops.colsum(self.DA_queue, qmean, self.DA_len, K, scale=1.0 / self.DA_len)
+        out = torch.empty_like(probs)
+        lib().da_apply(_p(probs), _p(qmean), _p(out), Bu, K, _stream())
+        return out
+
     def _mi_masks(self, B, mi_masks):
         dev = self.prototypes.device
         saint = self.hp.tabular_encoder == "saint"
@@ -261,11 +284,10 @@ class STiLModel(_Base):
             else:
                 mask_random = mask_random.to(device=dev, dtype=torch.uint8).contiguous()
             prototypes = self.prototypes.clone()
-            if hp.DA:
-                raise NotImplementedError("distribution alignment (DA: True) is not built yet; the reference default is False")
+            pred_in = self.distribution_alignment(ym_e[B_l:]) if hp.DA else None
             pl_, po_, pred, flags, hard_u, w3 = ops.cgpl_pgls(
                 ym_e[B_l:], yi_e[B_l:], yt_e[B_l:], feat_m_e[B_l:].contiguous(), prototypes, mask_random, float(hp.rate_pseudo), T, th,
-                use_pseudo, want_orig=True)
+                use_pseudo, want_orig=True, pred_in=pred_in)
             # hard label / confidence of pseudo_label_all = cat(one_hot(y_l), prediction)  (STiLModel.py:321)
             hard = torch.cat((y_l.to(torch.int32), hard_u))
             conf = torch.cat((torch.ones(B_l, dtype=torch.uint8, device=dev), flags[:, 2].contiguous()))
