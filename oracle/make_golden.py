@@ -232,6 +232,7 @@ CASES = {
                        8, 3, False, True),
 }
 
+VAL_KEYS = ["val_loss", "val_loss_ce", "val_loss_itc", "test_probs"]
 SCALARS = ["loss", "loss_ce", "loss_itc", "loss_club_i", "loss_club_i_est", "loss_club_t", "loss_club_t_est",
            "loss_pt", "loss_m_u", "loss_i_u", "loss_t_u"]
 TENSORS = ["y_hat_m", "y_hat_i", "y_hat_t", "x_si_enhance", "x_si", "x_ai", "x_st_enhance", "x_st", "x_at", "x_c",
@@ -346,6 +347,20 @@ def run_reference(hp, sd, batch, epoch, mask_random, mi_masks):
         opt.step()
     finally:
         nn.Dropout.forward, DT.drop_path, torch.rand_like = orig_dropout_fwd, orig_drop_path, orig_rand_like
+    # ---- inference hooks on the post-step model, eval mode (Lightning's validation / test loops)
+    model.model.forward_all, model.ema.forward_all, model.project_3features = fa_s, fa_e, p3
+    model.eval()
+    vx = [torch.cat((batch["l"][0][1], batch["u"][0][1])), torch.cat((batch["l"][1][1], batch["u"][1][1]))]
+    vy = torch.cat((batch["l"][2], batch["u"][2]))
+    model.logged = dict(model.logged)
+    with torch.no_grad():
+        vloss = model.validation_step((vx, vy), 0)
+        captured = {}
+        for nm in ("acc_test", "auc_test"):
+            getattr(model, nm).forward = (lambda p_, y_, _n=nm: captured.__setitem__(_n, p_.detach().clone()))
+        model.test_step((vx, vy), 0)
+    val = dict(val_loss=vloss.detach(), val_loss_ce=model.logged["multimodal.val.CEloss"], val_loss_itc=model.logged["multimodal.val.ITCloss"],
+               test_probs=captured["acc_test"])
     L = model.logged
     s, e = cap["s"], cap["e"]
     out = dict(loss=loss.detach(), loss_ce=L["multimodal.train.CEloss"], loss_itc=L["multimodal.train.ITCloss"],
@@ -361,6 +376,7 @@ def run_reference(hp, sd, batch, epoch, mask_random, mi_masks):
     out["feat_m_e"] = cap["p3"][1][0].detach()
     out["class_sum"] = model.prototypes_sum - ps0
     out["class_count"] = model.prototypes_count_sum - pc0
+    out.update(val)
     out = {k: (v.detach() if isinstance(v, torch.Tensor) else torch.tensor(v)) for k, v in out.items()}
     return out, grads, {k: v.detach().clone() for k, v in model.state_dict().items()}
 
@@ -391,6 +407,11 @@ def main():
         sd_o = {k: v.clone() for k, v in sd.items()}
         opt = {}
         o = O.full_step(sd_o, opt, 1, batch, hp, epoch, mask_random, mi_masks)
+        vx_img = torch.cat((batch["l"][0][1], batch["u"][0][1])); vx_tab = torch.cat((batch["l"][1][1], batch["u"][1][1]))
+        vy = torch.cat((batch["l"][2], batch["u"][2]))
+        ov = O.validation_step(sd_o, vx_img, vx_tab, vy, hp)
+        o["val_loss"], o["val_loss_ce"], o["val_loss_itc"] = ov["loss"], ov["loss_ce"], ov["loss_itc"]
+        o["test_probs"] = O.test_step(sd_o, vx_img, vx_tab, hp)
         # ---- pin: oracle == reference
         bad = []
         for k, v in ref_out.items():
@@ -423,6 +444,8 @@ def main():
         fx = {"meta_epoch": np.int64(epoch)}
         for k in SCALARS:
             fx["out_" + k] = (ref_out[k] if k in ref_out else o[k]).numpy().astype(np.float64)
+        for k in VAL_KEYS:
+            fx["out_" + k] = ref_out[k].numpy()
         for k in TENSORS:
             v = ref_out[k] if k in ref_out else o[k]  # masks / pseudo-labels are internal to training_step: oracle values, implied-checked via the losses + class_sum
             fx["out_" + k] = v.numpy()

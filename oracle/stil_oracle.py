@@ -666,6 +666,30 @@ def training_step(sd: Dict[str, Tensor], batch, hp, current_epoch: int,
     )
 
 
+def validation_step(sd, x_img, x_tab, y, hp):
+    """STiLModel.validation_step (STiLModel.py:424-474), module in eval mode (Lightning's validation loop)."""
+    with torch.no_grad():
+        o = backbone_forward_all(sd, "model.", x_img, x_tab, hp, train=False)
+        y_hat, y_i, y_t, si_e, si_m, ai, st_e, st_m, at, xc = o
+        feat_i = F.normalize(_head(sd, "projector_imaging.", ai))
+        feat_t = F.normalize(_head(sd, "projector_tabular.", at))
+        loss_itc, logits = clip_loss(feat_i, feat_t, hp.temperature, hp.lambda_0)
+        ci, ei = club_forward(sd, "CLUB_imaging.", si_m, ai)
+        ct, et = club_forward(sd, "CLUB_tabular.", st_m, at)
+        loss_ce = F.cross_entropy(y_hat, y)
+        loss = hp.alpha * loss_ce + hp.beta * loss_itc + hp.gamma * (ci + ei + ct + et)
+        return dict(loss=loss, loss_ce=loss_ce, loss_itc=loss_itc, y_hat=torch.softmax(y_hat, 1), y_i_hat=torch.softmax(y_i, 1),
+                    y_t_hat=torch.softmax(y_t, 1), itc_logits=logits)
+
+
+def test_step(sd, x_img, x_tab, hp):
+    """STiLModel.test_step (STiLModel.py:517-530): softmax of the multimodal logits (column 1 for binary tasks)."""
+    with torch.no_grad():
+        y_hat = backbone_forward_all(sd, "model.", x_img, x_tab, hp, train=False)[0]
+        p = torch.softmax(y_hat, dim=1)
+        return p[:, 1] if hp.num_classes == 2 else p
+
+
 def training_epoch_end(sd):
     """STiLModel.py:408-415: commit prototypes, zero accumulators."""
     with torch.no_grad():

@@ -355,7 +355,9 @@ class STiLModel(_Base):
         ct, et = self.CLUB_tabular.both(st_m, at)
         loss_ce = ops.CEHardFn.apply(y_hat.contiguous(), y.to(dev))
         loss = self.hp.alpha * loss_ce + self.hp.beta * loss_itc + self.hp.gamma * (ci + ei + ct + et)
-        self.log("multimodal.val.loss", loss)
+        for name, v in (("ITCloss", loss_itc), ("CLUBloss_imaging", ci), ("CLUBloss_imaging_est", ei), ("CLUBloss_tabular", ct),
+                        ("CLUBloss_tabular_est", et), ("CEloss", loss_ce), ("loss", loss)):
+            self.log(f"multimodal.val.{name}", v, on_epoch=True, on_step=False)
         return loss
 
     @torch.no_grad()

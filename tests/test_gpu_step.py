@@ -119,6 +119,16 @@ def test_training_step_matches_reference_golden(name):
             if abs(float(v.sum()) - float(fx[key])) > 5e-5 * (1.0 + ref_abs):
                 bad.append((key, float(v.sum()), float(fx[key])))
     assert not bad, f"{len(bad)} mismatches, first: {bad[:10]}"
+    # inference hooks on the post-step model (STiLModel.py:424-474, 517-533), eval-mode BatchNorm
+    vx = [torch.cat((batch["l"][0][1], batch["u"][0][1])).cuda(), torch.cat((batch["l"][1][1], batch["u"][1][1])).cuda()]
+    vy = torch.cat((batch["l"][2], batch["u"][2])).cuda()
+    vloss = m.validation_step((vx, vy), 0)
+    probs = m.test_step((vx, vy), 0)
+    logged = m.logged if hasattr(m, "logged") else {}
+    for key, val in (("val_loss", vloss), ("val_loss_ce", logged.get("multimodal.val.CEloss")), ("val_loss_itc", logged.get("multimodal.val.ITCloss")),
+                     ("test_probs", probs)):
+        ok, err = _close(val.detach().cpu().numpy(), fx["out_" + key], 2e-4)
+        assert ok, (key, err)
     assert float(np.median(ratios)) <= 1.0, f"median gradient error / tight bound = {np.median(ratios):.3f}"
     print(f"[{name}] gradient error / tight bound: median {np.median(ratios):.3f}, p90 {np.percentile(ratios, 90):.3f}, max {np.max(ratios):.3f}")
 
