@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--ncat", type=int, default=16)
     ap.add_argument("--ncon", type=int, default=48)
     ap.add_argument("--classes", type=int, default=286)
+    ap.add_argument("--variant", choices=["dvm", "saint", "cardiac"], default="dvm",
+                    help="dvm = BASELINE configs[1..2] (the bench line); saint = config 4; cardiac = config 5 (26 cat + 49 con, K=2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--breakdown", action="store_true", help="also print per-entry-point GPU time of the last step (stderr)")
@@ -78,10 +80,16 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path in the product)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    fl = [8] * a.ncat + [1] * a.ncon
+    extra = {}
+    if a.variant == "saint":
+        extra = dict(tabular_encoder="saint")
+    elif a.variant == "cardiac":  # configs/config_cardiac_STiL.yaml deltas
+        a.ncat, a.ncon, a.classes = 26, 49, 2
+        extra = dict(target="CAD", th1=0.85, beta=1.0, gamma=1.0, rate_pseudo=0.95, ema_momentum=0.4, lr_eval=1e-3)
+    fl = [(4 if a.variant == "cardiac" else 8)] * a.ncat + [1] * a.ncon
     torch.manual_seed(2022)
     m = STiLModel(dict(field_lengths=fl, num_classes=a.classes, img_size=a.img, batch_size=a.batch, start_epoch=35,
-                       repeat_ratio=1.0, seed=2022 + rank))
+                       repeat_ratio=1.0, seed=2022 + rank, **extra))
     m.setup_device(dev)
     m.train()
     m.current_epoch = 36  # > start_epoch: every loss term of STiLModel.py:345 is live
@@ -145,7 +153,7 @@ def main():
         out = dict(metric="training samples/sec (labeled+unlabeled) for DVM STiL", value=round(value, 2), unit="samples/s",
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload=f"config_dvm_STiL ResNet-50 + Transformer tabular, batch {a.batch}/GPU "
+                   config=dict(workload=f"config_{'cardiac' if a.variant == 'cardiac' else 'dvm'}_STiL{'_SAINT' if a.variant == 'saint' else ''} ResNet-50 + {'SAINT' if a.variant == 'saint' else 'Transformer'} tabular, batch {a.batch}/GPU "
                                         f"({a.batch // 8} labelled + {a.batch - a.batch // 8} unlabelled), {a.img}x{a.img} + "
                                         f"{a.ncat + a.ncon} columns, K={a.classes}, epoch > start_epoch, MI dropout on",
                                global_batch=a.batch * world, parallelism=f"dp{world}", precision="fp32-exact MFMA"),
@@ -171,7 +179,7 @@ def main():
             print("  gemm by shape (M, N, K, k, stride, mode; mode 2 = wgrad_tn): launches, ms, TFLOP/s", file=sys.stderr)
             for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:60]:
                 print(f"    {str(k):44s} {v[0]:3d} {v[1]:8.3f} ms {v[2] / v[1] / 1e9:7.1f} TF", file=sys.stderr)
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.variant == "dvm":
             out["cpu_baseline"] = cpu_baseline(fl, a.classes, a.img, a.cpu_batch)
         print(json.dumps(out), flush=True)
     if world > 1:
