@@ -50,6 +50,7 @@ int stil_gemm_nt_variant(int M, int N);
 /* tuning knob for A/B measurements: K-depth of the NT kernel's LDS tile (16 or 32; default 32) */
 int stil_set_gemm_bk(int bk);
 int stil_set_gemm_variant(int v);
+int stil_set_wgrad_variant(int v);
 
 /* Weight gradient  dW (+)= dY[M,N]^T . Xgather[M,K]  (split over M, slab partials + ordered reduce).
  * KH*KW > 1: dW is written in the reference layout (N, srcC, KH, KW); else [N, Kdst] (first Kdst columns). */

@@ -525,9 +525,19 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   return STIL_OK;
 }
 
+static int g_tn_variant = 0;   // 0 = automatic
+// tuning knob (A/B measurements only): block tile of the weight-gradient kernel, 22 = 128x128 (64x128 for N <= 64), 11 = 64x64
+extern "C" int stil_set_wgrad_variant(int v) {
+  if (v != 0 && v != 22 && v != 11) { stil_set_error("stil_set_wgrad_variant: bad variant %d", v); return STIL_EINVAL; }
+  g_tn_variant = v;
+  return STIL_OK;
+}
+// measured (tests/tools/gemm_bench.py): 64x64 tiles win for N <= 256 (more blocks, fewer M-splits, less slab traffic)
+static inline int tn_variant(int N) { return g_tn_variant ? g_tn_variant : (N <= 256 ? 11 : 22); }
 static int wgrad_splits(int M, int N, int K) {
-  int tiles = cdiv(N, N <= 64 ? 64 : 128) * cdiv(K, 128);
-  int want = cdiv(768, tiles);
+  const int tv = tn_variant(N);
+  int tiles = tv == 11 ? cdiv(N, 64) * cdiv(K, 64) : cdiv(N, N <= 64 ? 64 : 128) * cdiv(K, 128);
+  int want = cdiv(tv == 11 ? 2304 : 768, tiles);
   int maxs = M / 256 > 0 ? M / 256 : 1;
   int s = want < maxs ? want : maxs;
   if (s < 1) s = 1;
@@ -559,7 +569,11 @@ extern "C" int stil_wgrad_tn(const float* dY, const float* X, float* dW, int M, 
   p.vecX = is_vec(X, ldx) && (srcC % 4 == 0);
   hipStream_t s = (hipStream_t)stream;
   const bool vec = p.vecY && p.vecX && (N % 4 == 0) && (K % 4 == 0);
-  if (N <= 64) {
+  if (tn_variant(N) == 11) {
+    dim3 grid(cdiv(N, 64) * cdiv(K, 64), 1, splits);
+    if (vec) hipLaunchKernelGGL((gemm_tn_kernel<1, 1, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_tn_kernel<1, 1, false>), grid, dim3(256), 0, s, p);
+  } else if (N <= 64) {
     dim3 grid(cdiv(N, 64) * cdiv(K, 128), 1, splits);
     if (vec) hipLaunchKernelGGL((gemm_tn_kernel<1, 2, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((gemm_tn_kernel<1, 2, false>), grid, dim3(256), 0, s, p);

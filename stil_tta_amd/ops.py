@@ -297,7 +297,9 @@ def strided_dgrad(dy, w, Nb, H, W_, Cin, OH, OW, Cout, k, stride, pad):
     (s*oy'+py, s*ox'+px) only see taps ky = ky0 + s*j with ky0 = (py+pad) % s, so no multiply-by-zero work is done
     (the generic mode-1 gather computes s*s times the algorithmic MACs)."""
     dev = dy.device
-    dx = torch.zeros((Nb * H * W_, Cin), dtype=torch.float32, device=dev)  # phases without taps (1x1 s2) stay zero
+    # every output pixel belongs to exactly one phase; phases without taps (1x1 s2: 3 of 4) must read as zero
+    all_covered = all(len(range((p_ + pad) % stride, k, stride)) > 0 for p_ in range(stride))
+    dx = (torch.empty if all_covered else torch.zeros)((Nb * H * W_, Cin), dtype=torch.float32, device=dev)
     for py in range(stride):
         ky0 = (py + pad) % stride
         KHs = len(range(ky0, k, stride))
@@ -441,7 +443,8 @@ class AttentionFn(torch.autograd.Function):
         B, T, three = qkv.shape
         d = three // (3 * H)
         scale = d ** -0.5
-        out = torch.zeros((B, T, H * d), dtype=torch.float32, device=qkv.device)
+        covered = sum(w_[1] for w_ in windows) == T  # query windows are disjoint: every output row written once
+        out = (torch.empty if covered else torch.zeros)((B, T, H * d), dtype=torch.float32, device=qkv.device)
         probs = []
         for wi, (qo, Sq, ko, Skv) in enumerate(windows):
             pr = torch.empty((B, H, Sq, Skv), dtype=torch.float32, device=qkv.device)

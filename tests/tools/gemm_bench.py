@@ -46,3 +46,34 @@ print(f"{'shape':46s} " + " ".join(f"{n:>10s}" for n, _ in variants))
 for sh in NT:
     print(f"{str(sh):46s} " + " ".join(f"{max(res[(n, sh)]):10.1f}" for n, _ in variants))
 L.set_gemm_variant(0)
+
+# ---- weight-gradient (TN) kernel: tile variants
+TN = [(50176, 256, 2304, 3, 14), (802816, 64, 576, 3, 56), (802816, 256, 64, 1, 56), (200704, 128, 1152, 3, 28), (50176, 1024, 256, 1, 14),
+      (16640, 512, 2048, 1, 0), (12544, 512, 4608, 3, 7), (200704, 512, 128, 1, 28), (3211264, 64, 160, 1, 0)]
+def run_tn(shape):
+    M, N, K, k, H = shape
+    dY = torch.randn(M, N, device=dev)
+    if k == 1:
+        X = torch.randn(M, K, device=dev); geom = None
+    else:
+        C = K // 9; X = torch.randn(M // (H * H), H, H, C, device=dev); geom = (H, H, C, H, H, 3, 3, 1, 1)
+    dW = torch.empty(N, K, device=dev) if k == 1 else torch.empty(N, K // 9, 3, 3, device=dev)
+    ops.wgrad_tn(dY, X, dW, M, N, K, geom=geom)
+    torch.cuda.synchronize()
+    s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s0.record()
+    for _ in range(rounds):
+        ops.wgrad_tn(dY, X, dW, M, N, K, geom=geom)
+    e0.record(); torch.cuda.synchronize()
+    ms = s0.elapsed_time(e0) / rounds
+    return ms, 2.0 * M * N * K / ms / 1e9
+res = {}
+for r in range(2):
+    for v in (22, 11):
+        L.set_wgrad_variant(v)
+        for sh in TN:
+            res.setdefault((v, sh), []).append(run_tn(sh)[1])
+print(f"{'wgrad shape':46s}       t22        t11")
+for sh in TN:
+    print(f"{str(sh):46s} {max(res[(22, sh)]):10.1f} {max(res[(11, sh)]):10.1f}")
+L.set_wgrad_variant(0)
