@@ -45,6 +45,7 @@ def parse():
                     help="dvm = BASELINE configs[1..2] (the bench line); saint = config 4; cardiac = config 5 (26 cat + 49 con, K=2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (driver.GraphedTrainStep)")
     ap.add_argument("--breakdown", action="store_true", help="also print per-entry-point GPU time of the last step (stderr)")
     return ap.parse_args()
 
@@ -98,6 +99,11 @@ def main():
     opt = StilAdam(m.flat, lr=1e-4)
     batch = synthetic_batch(fl, a.classes, a.batch, a.img, seed=2022 + rank, device=dev)
 
+    if a.graph:
+        from stil_tta_amd.driver import GraphedTrainStep
+        gstep = GraphedTrainStep(m, opt, batch, warmup=max(1, a.warmup))
+        eager_step = train_step
+        train_step = lambda m_, o_, b_: gstep(b_)  # noqa: E731
     for _ in range(a.warmup):
         train_step(m, opt, batch)
     if world > 1:
@@ -109,7 +115,10 @@ def main():
     for s in range(a.steps):
         if s == a.steps - 1:
             L.begin_profile()  # HIP events around every C-ABI launch of the last timed step (same stream)
-        train_step(m, opt, batch)
+        if a.graph and s == a.steps - 1:
+            eager_step(m, opt, batch)  # per-launch events need eager launches: the profiled last step runs eagerly
+        else:
+            train_step(m, opt, batch)
         if s == a.steps - 1:
             torch.cuda.synchronize()
             prof = L.end_profile()
@@ -156,7 +165,8 @@ def main():
                    config=dict(workload=f"config_{'cardiac' if a.variant == 'cardiac' else 'dvm'}_STiL{'_SAINT' if a.variant == 'saint' else ''} ResNet-50 + {'SAINT' if a.variant == 'saint' else 'Transformer'} tabular, batch {a.batch}/GPU "
                                         f"({a.batch // 8} labelled + {a.batch - a.batch // 8} unlabelled), {a.img}x{a.img} + "
                                         f"{a.ncat + a.ncon} columns, K={a.classes}, epoch > start_epoch, MI dropout on",
-                               global_batch=a.batch * world, parallelism=f"dp{world}", precision="fp32-exact MFMA"),
+                               global_batch=a.batch * world, parallelism=f"dp{world}", precision="fp32-exact MFMA",
+                               launch="hipGraph replay" if a.graph else "eager"),
                    roofline=roof, loss=round(loss, 5))
         if fps:
             out["step_tflops_algorithmic"] = round(value * fps / 1e12, 2)

@@ -115,8 +115,11 @@ int stil_act_bwd(const float* dy, const float* ref, float* dx, long n, int kind,
 int stil_drop_add(const float* x, const float* resid, const unsigned char* emask, const unsigned char* rmask,
                   float* out, long n, int rowlen, float scale, void* stream);
 int stil_axpby(const float* x, const float* y, float* out, long n, float a, float b, void* stream);
+/* keep-mask = hash(seed, *step_dev, offset + i) >= p; the per-step counter is read from DEVICE memory (bumped by
+ * stil_counter_inc once per step) so that a captured hipGraph draws fresh masks on every replay */
 int stil_rng_mask(unsigned char* out, long n, unsigned long long seed, unsigned long long offset, float p,
-                  void* stream);
+                  const unsigned long long* step_dev, void* stream);
+int stil_counter_inc(unsigned long long* counter_dev, void* stream);
 int stil_tab_embed_fwd(const float* x, const int* cat_offsets, const float* cat_emb, const float* con_w,
                        const float* con_b, const float* cls, const float* colemb, float* h, int B,
                        int ncols, int ncat, int D, void* stream);

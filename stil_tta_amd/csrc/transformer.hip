@@ -295,13 +295,17 @@ __device__ __forceinline__ unsigned int hash_u32(unsigned long long x) {
   return (unsigned int)(x >> 16);
 }
 __global__ void rng_mask_kernel(unsigned char* __restrict__ out, long n, unsigned long long seed,
-                                unsigned long long offset, float p) {
+                                unsigned long long offset, float p, const unsigned long long* __restrict__ step) {
+  // the per-step part of the counter lives in DEVICE memory so that a captured hipGraph draws fresh masks on replay
+  const unsigned long long st = step ? step[0] * 0xD1B54A32D192ED03ULL : 0ULL;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    unsigned int r = hash_u32(seed * 0x9E3779B97F4A7C15ULL + offset + (unsigned long long)i);
+    unsigned int r = hash_u32(seed * 0x9E3779B97F4A7C15ULL + st + offset + (unsigned long long)i);
     float u = (float)(r >> 8) * (1.0f / 16777216.0f);
     out[i] = u >= p ? 1 : 0;
   }
 }
+
+__global__ void counter_inc_kernel(unsigned long long* c) { if (threadIdx.x == 0 && blockIdx.x == 0) c[0] += 1; }
 
 // out[c][r] = in[r][c]
 __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
@@ -559,10 +563,17 @@ extern "C" int stil_axpby(const float* x, const float* y, float* out, long n, fl
   return STIL_OK;
 }
 
+extern "C" int stil_counter_inc(unsigned long long* counter_dev, void* stream) {
+  STIL_REQUIRE(counter_dev, "stil_counter_inc: null pointer");
+  hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter_dev);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
 extern "C" int stil_rng_mask(unsigned char* out, long n, unsigned long long seed, unsigned long long offset, float p,
-                             void* stream) {
+                             const unsigned long long* step_dev, void* stream) {
   STIL_REQUIRE(out && p >= 0.f && p < 1.f, "stil_rng_mask: bad arguments");
-  hipLaunchKernelGGL(rng_mask_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset, p);
+  hipLaunchKernelGGL(rng_mask_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset, p, step_dev);
   STIL_LAUNCH_CHECK();
   return STIL_OK;
 }

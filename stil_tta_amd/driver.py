@@ -112,3 +112,60 @@ def synthetic_batch(field_lengths, num_classes: int, B: int, img_size: int, seed
                 torch.full((n,), lab, dtype=torch.bool, device=device))
 
     return {"l": part(slice(0, B_l), True), "u": part(slice(B_l, B), False)}
+
+
+class GraphedTrainStep:
+    """The whole optimisation step (zero_grad -> training_step -> backward -> all-reduce -> Adam) captured ONCE into a
+    hipGraph and replayed: ~1500 kernel launches per step collapse into one graph launch, which is what matters when
+    the per-GPU batch is small (BASELINE config 1: B = 32, config 5: B = 16 per GPU) and eager launches go host-bound.
+
+    Static shapes only; the batch is copied into static device buffers before each replay.  Everything that varies per
+    step lives in device memory (mask-RNG step counter, Adam step counts); what is baked in at capture -- learning rate,
+    `current_epoch > start_epoch`, the set of parameters that receive gradients -- is watched, and a change triggers a
+    re-capture.  Not supported: `DA: True` (host read of the queue pointer, as in the reference).
+    """
+
+    def __init__(self, model, optimizer, example_batch, warmup: int = 2):
+        self.model, self.optimizer = model, optimizer
+        model.setup_device()
+        dev = model.prototypes.device
+        self.static = {k: ([v[0][0].to(dev).clone(), v[0][1].to(dev).clone()], [v[1][0].to(dev).clone(), v[1][1].to(dev).clone()],
+                           v[2].to(dev).clone(), v[3].to(dev).clone(), v[4].to(dev).clone()) for k, v in example_batch.items()}
+        self.warmup = warmup
+        self.graph = None
+        self._key = None
+
+    def _signature(self):
+        g = self.optimizer.param_groups[0]
+        return (float(g["lr"]), self.model.current_epoch > self.model.hp.start_epoch, self.model.flat._active_host)
+
+    def _snapshot(self):
+        m, f = self.model, self.model.flat
+        tensors = [f.params, f.grads, f.exp_avg, f.exp_avg_sq, f.ema, f.steps, m.prototypes_sum, m.prototypes_count_sum, m._rng_step]
+        tensors += list(f.s_counters) + list(f.t_counters)
+        return [(t, t.clone()) for t in tensors]
+
+    def _capture(self):
+        snap = self._snapshot()  # warm-up steps are real optimisation steps: their effect is rolled back below
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # eager warm-up on a side stream (allocator + lazy one-time setup), as PyTorch requires
+            for _ in range(self.warmup):
+                train_step(self.model, self.optimizer, self.static)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):  # records the step; nothing executes until replay()
+            self.loss = train_step(self.model, self.optimizer, self.static)
+        self._key = self._signature()
+        for t, c in snap:
+            t.copy_(c)
+
+    def __call__(self, batch):
+        for k in ("l", "u"):
+            s, b = self.static[k], batch[k]
+            s[0][1].copy_(b[0][1], non_blocking=True); s[1][1].copy_(b[1][1], non_blocking=True); s[2].copy_(b[2], non_blocking=True)
+        if self.graph is None or self._key != self._signature():
+            self._capture()
+        self.graph.replay()
+        return self.loss

@@ -257,7 +257,10 @@ def fuse_mi_masks(m: Dict[str, torch.Tensor], device) -> Dict[str, torch.Tensor]
     return out
 
 
-def random_mi_masks(B, Ni, Nt, C, H, p, seed, offset, device) -> Dict[str, torch.Tensor]:
+_stream_idx_cache = {}
+
+
+def random_mi_masks(B, Ni, Nt, C, H, p, seed, offset, device, step=None) -> Dict[str, torch.Tensor]:
     """Train-mode stochasticity of the MI layer drawn on the device (counter-based hash RNG)."""
     T = 1 + Ni + Nt
     o = [offset]
@@ -266,13 +269,16 @@ def random_mi_masks(B, Ni, Nt, C, H, p, seed, offset, device) -> Dict[str, torch
         n = 1
         for s in shape:
             n *= s
-        t = ops.rng_mask(shape, p, seed, o[0], device)
+        t = ops.rng_mask(shape, p, seed, o[0], device, step)
         o[0] += n
         return t
 
     out = {"attn_i": draw(B, H, Ni, Ni), "attn_t": draw(B, H, Nt, Nt), "attn_c": draw(B, H, 1, T),
            "proj": draw(B, T, C), "fc1": draw(B, T, C), "fc2": draw(B, T, C)}
-    idx = torch.cat([torch.zeros(1, dtype=torch.long), torch.ones(Ni, dtype=torch.long), torch.full((Nt,), 2, dtype=torch.long)]).to(device)
+    idx = _stream_idx_cache.get((Ni, Nt, str(device)))
+    if idx is None:  # built once: an H2D copy per step could not be captured into a hipGraph
+        idx = torch.cat([torch.zeros(1, dtype=torch.long), torch.ones(Ni, dtype=torch.long), torch.full((Nt,), 2, dtype=torch.long)]).to(device)
+        _stream_idx_cache[(Ni, Nt, str(device))] = idx
     for k in ("dp1", "dp2"):
         out[k] = draw(B, 3)[:, idx].contiguous()
     return out

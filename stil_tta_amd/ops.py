@@ -124,9 +124,9 @@ def axpby(x, y, a, b, out=None):
     return out
 
 
-def rng_mask(shape, p, seed, offset, device):
+def rng_mask(shape, p, seed, offset, device, step=None):
     out = torch.empty(shape, dtype=torch.uint8, device=device)
-    lib().rng_mask(_p(out), out.numel(), int(seed), int(offset), float(p), _stream())
+    lib().rng_mask(_p(out), out.numel(), int(seed), int(offset), float(p), _p(step), _stream())
     return out
 
 
@@ -740,6 +740,20 @@ def cgpl_pgls(zm, zi, zt, feat_u, prototypes, mask_random, rate_pseudo, T, th, u
     return pl, po, pred, flags, hard, w3
 
 
+_ptr_tables = {}
+
+
+def _ptr_table(tensors, device):
+    """Device array of data pointers, cached: slab-backed tensors never move, and an H2D copy per step could not be
+    captured into a hipGraph."""
+    key = tuple(t.data_ptr() for t in tensors)
+    tb = _ptr_tables.get(key)
+    if tb is None:
+        tb = torch.tensor(list(key), dtype=torch.int64, device=device)
+        _ptr_tables[key] = tb
+    return tb
+
+
 # ------------------------------------------------------------------------------------------ SAINT tabular encoder
 class SaintEmbedColMlpFn(torch.autograd.Function):
     """Token buffer [B, nfeats, d] of DisCoAttentionBackbone.forward_tabular (STiLModel_SAINT_backbone.py:159-178):
@@ -756,7 +770,7 @@ class SaintEmbedColMlpFn(torch.autograd.Function):
         lib().saint_embed_fwd(_p(x), _p(meta["cat_cols"]), _p(meta["offs"]), _p(embeds), _p(pos), _p(out), B, ncols, ncat,
                               nfeats, d, _stream())
         if ncon:
-            ptrs = torch.tensor([t.data_ptr() for t in mlp_params], dtype=torch.int64, device=x.device)
+            ptrs = _ptr_table(mlp_params, x.device)
             lib().colmlp_fwd(_p(x), _p(meta["con_cols"]), _p(ptrs), _p(out), B, ncols, ncon, nfeats, ncat + 1, hid, d, _stream())
             ctx.ptrs = ptrs
         ctx.save_for_backward(x, embeds, pos, *mlp_params)
@@ -779,7 +793,7 @@ class SaintEmbedColMlpFn(torch.autograd.Function):
         lib().saint_embed_bwd(_p(g), _p(x), _p(meta["cat_cols"]), _p(meta["offs"]), _p(meta["rowcol"]), embeds.shape[0],
                               _p(outs[0]), _p(outs[1]), B, ncols, ncat, nfeats, d, acc, _stream())
         if ncon:
-            gptrs = torch.tensor([t.data_ptr() for t in outs[2:]], dtype=torch.int64, device=x.device)
+            gptrs = _ptr_table(outs[2:], x.device) if use_slab else torch.tensor([t.data_ptr() for t in outs[2:]], dtype=torch.int64, device=x.device)
             lib().colmlp_bwd(_p(g), _p(x), _p(meta["con_cols"]), _p(ctx.ptrs), _p(gptrs), B, ncols, ncon, nfeats, ncat + 1, hid,
                              d, acc, _stream())
         if use_slab:

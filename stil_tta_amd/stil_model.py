@@ -176,6 +176,7 @@ class STiLModel(_Base):
         device = torch.device(device or "cuda")
         nn.Module.to(self, device)
         teacher = self.ema if self.use_ema else self._backbone_cls(self.hp, self.field_lengths).to(device)
+        self._rng_step = torch.zeros(1, dtype=torch.int64, device=device)  # device-side step counter of the mask RNG
         self.flat = FlatState(self.model, teacher, [self.projector_imaging, self.projector_tabular, self.projector_multimodal,
                                                     self.CLUB_imaging, self.CLUB_tabular], device)
         return self
@@ -236,12 +237,12 @@ class STiLModel(_Base):
         C = self.hp.multimodal_embedding_dim
         out = {}
         for li in range(self.hp.multimodal_transformer_num_layers):
-            out[li] = random_mi_masks(B, Ni, Nt, C, 4, 0.1, self.hp.seed, self._rng_offset, dev)
+            out[li] = random_mi_masks(B, Ni, Nt, C, 4, 0.1, self.hp.seed, self._rng_offset, dev, self._rng_step)
             self._rng_offset += 4 * B * (1 + Ni + Nt) * (C + 4 * (1 + Ni + Nt))
         if saint:  # ff_dropout = 0.8 of the SAINT column / row feed-forwards (STiLModel_SAINT_backbone.py:120-122)
             nf, h4 = Nt + 1, 4 * 32
-            out["saint"] = {"ff_col": ops.rng_mask((B, nf, h4), 0.8, self.hp.seed + 2, self._rng_offset, dev),
-                            "ff_row": ops.rng_mask((B, nf * h4), 0.8, self.hp.seed + 3, self._rng_offset, dev)}
+            out["saint"] = {"ff_col": ops.rng_mask((B, nf, h4), 0.8, self.hp.seed + 2, self._rng_offset, dev, self._rng_step),
+                            "ff_row": ops.rng_mask((B, nf * h4), 0.8, self.hp.seed + 3, self._rng_offset, dev, self._rng_step)}
             self._rng_offset += B * nf * h4
         return out
 
@@ -264,6 +265,7 @@ class STiLModel(_Base):
         K, T, th = hp.num_classes, float(hp.temperature), float(hp.th1)
         use_pseudo = current_epoch > hp.start_epoch
         cache = {}
+        self._rng_offset = 0  # call-site offsets inside this step; the step itself is counted on the device (_rng_step)
 
         masks = self._mi_masks(B, mi_masks)
         s = self.model.forward_all((x_img, x_tab), train=True, mi_masks=masks, cache=cache)
@@ -279,7 +281,7 @@ class STiLModel(_Base):
             else:
                 ym_e, yi_e, yt_e, feat_m_e = y_m.detach(), y_i.detach(), y_t.detach(), feat_m.detach()
             if mask_random is None:
-                mask_random = ops.rng_mask((B_u,), 0.5, hp.seed + 1, self._rng_offset, dev)
+                mask_random = ops.rng_mask((B_u,), 0.5, hp.seed + 1, self._rng_offset, dev, self._rng_step)
                 self._rng_offset += B_u
             else:
                 mask_random = mask_random.to(device=dev, dtype=torch.uint8).contiguous()
@@ -314,6 +316,7 @@ class STiLModel(_Base):
                 dist.all_reduce(cs, op=dist.ReduceOp.SUM)  # ONE fused [K, Dp+1] collective instead of the reference's two
             lib().proto_add(_p(cs), _p(self.prototypes_sum), _p(self.prototypes_count_sum), K, hp.projection_dim, _stream())
 
+        lib().counter_inc(_p(self._rng_step), _stream())
         bs = B
         for name, v in (("CEloss", loss_ce), ("CEloss_unlabelled_m", loss_m_u), ("CEloss_unlabelled_i", loss_i_u),
                         ("CEloss_unlabelled_t", loss_t_u), ("ITCloss", loss_itc), ("CLUBloss_imaging", club_i),

@@ -428,6 +428,13 @@ def test_rng_mask_rate_and_determinism(ops):
     c = ops.rng_mask((1 << 20,), 0.1, 7, 1 << 20, "cuda")
     assert torch.equal(a, b) and not torch.equal(a, c)
     assert abs(float(a.float().mean()) - 0.9) < 2e-3
+    from stil_tta_amd._lib import lib
+    from stil_tta_amd.ops import _p, _stream
+    step = torch.zeros(1, dtype=torch.int64, device="cuda")
+    d0 = ops.rng_mask((1 << 16,), 0.1, 7, 0, "cuda", step)
+    lib().counter_inc(_p(step), _stream())
+    d1 = ops.rng_mask((1 << 16,), 0.1, 7, 0, "cuda", step)
+    assert torch.equal(d0, a[: 1 << 16]) and not torch.equal(d0, d1) and int(step) == 1
 
 
 def test_saint_pieces(ops):

@@ -259,3 +259,34 @@ def test_empty_and_ragged_inputs_fail_loudly():
         ops.L2NormFn.apply(torch.randn(8, 4, device="cuda").t())
     with pytest.raises(RuntimeError):  # conv with Cin not a multiple of 16
         ops.gemm_nt(torch.randn(9, 3, device="cuda"), torch.randn(4, 27, device="cuda"), 9, 4, 27, geom=(3, 3, 3, 3, 3, 3, 3, 1, 1, 0))
+
+
+def test_graphed_step_replays_the_eager_step_bit_for_bit():
+    """hipGraph capture of the whole step (driver.GraphedTrainStep): same kernels, same order -> identical bits,
+    including fresh dropout masks per replay (device-side RNG step counter)."""
+    from stil_tta_amd import STiLModel
+    from stil_tta_amd.driver import train_step, synthetic_batch, GraphedTrainStep
+    from stil_tta_amd.flat import StilAdam
+    fl = [3, 4] + [1] * 3
+
+    def make():
+        torch.manual_seed(0)
+        m = STiLModel(dict(model="resnet18", embedding_dim=512, field_lengths=fl, num_classes=5, start_epoch=0, batch_size=16, th1=0.3))
+        m.setup_device("cuda"); m.train(); m.current_epoch = 1
+        m.prototypes.copy_(torch.nn.functional.normalize(torch.randn(5, 128, generator=torch.Generator().manual_seed(1))).cuda())
+        return m, StilAdam(m.flat, lr=1e-3)
+
+    batches = [synthetic_batch(fl, 5, 16, 64, seed=s, device="cuda") for s in range(6)]
+    me, oe = make()
+    mg, og = make()
+    gs = GraphedTrainStep(mg, og, batches[0], warmup=2)  # capture (incl. its warm-up steps) leaves the state untouched
+    masks_seen = []
+    for b in batches:
+        le = train_step(me, oe, b)
+        lg = gs(b)
+        torch.cuda.synchronize()
+        assert torch.equal(le, lg), (float(le), float(lg))
+        masks_seen.append(mg.last["mask_random"].clone())
+    assert torch.equal(me.flat.params, mg.flat.params) and torch.equal(me.flat.ema, mg.flat.ema)
+    assert torch.equal(me.prototypes_sum, mg.prototypes_sum)
+    assert any(not torch.equal(masks_seen[0], m_) for m_ in masks_seen[1:]), "replays must draw fresh random masks"
