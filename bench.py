@@ -79,6 +79,7 @@ def main():
 
     rank, world, local = init_distributed()
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path in the product)"
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     extra = {}

@@ -32,10 +32,10 @@ def init_distributed(backend: Optional[str] = None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+        if backend is None:  # "nccl" is RCCL on ROCm; STIL_DIST_BACKEND=gloo lets several ranks share one GPU (tests)
+            backend = os.environ.get("STIL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
@@ -59,8 +59,19 @@ def allreduce_flat(slab: torch.Tensor, bucket_elems: int = 64 << 20):
     return 1.0 / w
 
 
+def sync_buffers(model):
+    """DDP broadcast_buffers semantics: every rank starts the step with rank 0's BN running statistics (student and
+    EMA teacher); two contiguous broadcasts of the buffer ranges of the flat slabs."""
+    if world_size() == 1:
+        return
+    model.setup_device()
+    for slab in model.flat.buffer_slabs():
+        dist.broadcast(slab, src=0)
+
+
 def train_step(model, optimizer, batch, mask_random=None, mi_masks=None):
     """One optimisation step. Returns the (detached) loss tensor; no host sync."""
+    sync_buffers(model)
     optimizer.zero_grad()
     loss = model.training_step(batch, 0, mask_random=mask_random, mi_masks=mi_masks)
     loss.backward()

@@ -97,6 +97,12 @@ class FlatState:
         if self.s_counters:
             torch._foreach_copy_(self.t_counters, self.s_counters)
 
+    def buffer_slabs(self):
+        """Student / teacher float buffers (BN running stats), each one contiguous range: what DDP's default
+        broadcast_buffers=True re-sends from rank 0 before every forward (the reference trains under Lightning DDP)."""
+        a, b = self.n_backbone_params, self.n_backbone_state
+        return [self.params[a:b], self.ema[a:b]] if b > a else []
+
     # ---- gradients
     def zero_grad(self):
         self.grads.zero_()

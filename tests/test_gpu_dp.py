@@ -1,0 +1,85 @@
+"""Data-parallel semantics on the GPU: two ranks (gloo, sharing the one GPU of the test box) run
+driver.train_step on their shards; the all-reduced gradient slab must equal the SUM of the two single-process shard
+gradients, the fused prototype exchange the sum of the shard class sums, and both ranks must end the step with
+bit-identical parameters (Adam consumes grad_sum / world); BN running statistics follow DDP's broadcast_buffers
+(rank 0's values at the start of the next step)."""
+import os
+import sys
+import tempfile
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FL = [3, 4] + [1] * 3
+HP = dict(model="resnet18", embedding_dim=512, field_lengths=FL, num_classes=5, start_epoch=0, batch_size=16, th1=0.3, mi_dropout=False)
+
+
+def _make():
+    from stil_tta_amd import STiLModel
+    from stil_tta_amd.flat import StilAdam
+    torch.manual_seed(0)
+    m = STiLModel(dict(HP))
+    m.setup_device("cuda"); m.train(); m.current_epoch = 1
+    m.prototypes.copy_(torch.nn.functional.normalize(torch.randn(5, 128, generator=torch.Generator().manual_seed(1))).cuda())
+    return m, StilAdam(m.flat, lr=1e-3)
+
+
+def _worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      STIL_DIST_BACKEND="gloo")
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from stil_tta_amd.driver import init_distributed, shard_batch, synthetic_batch, sync_buffers, train_step
+    init_distributed()
+    m, opt = _make()
+    batch = shard_batch(synthetic_batch(FL, 5, 32, 64, seed=3, device="cuda"), rank, world)
+    mr = (torch.arange(7) % 2 == rank).cuda()
+    train_step(m, opt, batch, mask_random=mr)
+    torch.cuda.synchronize()
+    out = dict(grads=m.flat.grads.cpu(), params=m.flat.params.cpu(), psum=m.prototypes_sum.cpu(), pcnt=m.prototypes_count_sum.cpu(),
+               buf=(m.flat.n_backbone_params, m.flat.n_backbone_state))
+    sync_buffers(m)  # what the next step starts with: rank 0's BN running statistics (DDP broadcast_buffers)
+    torch.cuda.synchronize()
+    out.update(params_synced=m.flat.params.cpu(), ema_synced=m.flat.ema.cpu())
+    torch.save(out, os.path.join(outdir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_sum_of_shards():
+    from stil_tta_amd.driver import shard_batch, synthetic_batch
+    with tempfile.TemporaryDirectory() as td:
+        ctx = mp.get_context("spawn")
+        port = 29800 + os.getpid() % 100
+        ps = [ctx.Process(target=_worker, args=(r, 2, port, td)) for r in range(2)]
+        for p in ps:
+            p.start()
+        for p in ps:
+            p.join(timeout=300)
+            assert p.exitcode == 0
+        r0, r1 = torch.load(os.path.join(td, "rank0.pt")), torch.load(os.path.join(td, "rank1.pt"))
+    a, b = r0["buf"]
+    assert torch.equal(r0["params"][:a], r1["params"][:a]) and torch.equal(r0["params"][b:], r1["params"][b:]), "ranks diverged"
+    assert not torch.equal(r0["params"][a:b], r1["params"][a:b])  # BN running stats are per-shard until the next sync
+    assert torch.equal(r0["params_synced"], r1["params_synced"]) and torch.equal(r0["ema_synced"], r1["ema_synced"])
+    assert torch.equal(r0["params_synced"], r0["params"])  # rank 0 is the source
+    assert torch.equal(r0["grads"], r1["grads"]) and torch.equal(r0["psum"], r1["psum"])
+    # single-process reference: each shard alone (no process group), gradients / class sums added by hand
+    full = synthetic_batch(FL, 5, 32, 64, seed=3, device="cuda")
+    gsum, psum, pcnt = None, None, None
+    for rank in range(2):
+        m, opt = _make()
+        m.flat.zero_grad()
+        loss = m.training_step(shard_batch(full, rank, 2), 0, mask_random=(torch.arange(7) % 2 == rank).cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+        g = m.flat.grads.cpu()
+        gsum = g if gsum is None else gsum + g
+        psum = m.prototypes_sum.cpu() if psum is None else psum + m.prototypes_sum.cpu()
+        pcnt = m.prototypes_count_sum.cpu() if pcnt is None else pcnt + m.prototypes_count_sum.cpu()
+    scale = float(gsum.abs().max())
+    assert float((r0["grads"] - gsum).abs().max()) <= 1e-6 * (1 + scale)
+    assert float((r0["psum"] - psum).abs().max()) <= 1e-5 and torch.equal(r0["pcnt"], pcnt)
