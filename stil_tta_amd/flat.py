@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from ._lib import lib
-from .ops import _p, _stream
+from .ops import _p, _stream, join_side
 
 ALIGN = 1024
 
@@ -42,7 +42,7 @@ class FlatState:
         self.n_backbone_params = sum(_round_up(p.numel()) for _, p in s_params)
         self.n_backbone_state = self.n_backbone_params + sum(_round_up(b.numel()) for _, b in s_bufs)
         self.params = torch.zeros(self.total, dtype=torch.float32, device=device)
-        self.grads = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self._grads = torch.zeros(self.total, dtype=torch.float32, device=device)
         self.exp_avg = torch.zeros(self.total, dtype=torch.float32, device=device)
         self.exp_avg_sq = torch.zeros(self.total, dtype=torch.float32, device=device)
         self.ema = torch.zeros(self.n_backbone_state, dtype=torch.float32, device=device)
@@ -55,7 +55,7 @@ class FlatState:
             t.data = view
             is_param = i < len(s_params) or i >= len(s_params) + len(s_bufs)
             if is_param:
-                t._gslot = self.grads[o:o + n].view(t.shape)
+                t._gslot = self._grads[o:o + n].view(t.shape)
                 t._stil_touched = False
                 t.grad = None
                 tid = len(self.tensors)
@@ -104,6 +104,12 @@ class FlatState:
         return [self.params[a:b], self.ema[a:b]] if b > a else []
 
     # ---- gradients
+    @property
+    def grads(self) -> torch.Tensor:
+        """The gradient slab; reading it joins the side stream the weight-gradient GEMMs run on (ops.wgrad_param)."""
+        join_side()
+        return self._grads
+
     def zero_grad(self):
         self.grads.zero_()
         for t in self.tensors:
@@ -112,6 +118,7 @@ class FlatState:
 
     def publish_grads(self):
         """Expose the slab views as .grad (for inspection / tests / foreign optimizers)."""
+        join_side()
         for t in self.tensors:
             t.grad = t._gslot if t._stil_touched else None
 

@@ -36,21 +36,56 @@ def _chk(*ts):
 
 
 class _Workspace:
-    """One grow-only scratch buffer per device (all kernels run on one stream, so reuse is ordered)."""
+    """One grow-only scratch buffer per (device, stream): launches of one stream are ordered, so reuse is safe."""
 
     def __init__(self):
         self.buf = {}
 
     def get(self, nbytes: int, device) -> torch.Tensor:
         nbytes = max(int(nbytes), 256)
-        b = self.buf.get(device)
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        b = self.buf.get(key)
         if b is None or b.numel() < nbytes:
             b = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
-            self.buf[device] = b
+            self.buf[key] = b
         return b
 
 
 _ws = _Workspace()
+
+
+class _SideStream:
+    """Weight-gradient GEMMs leave the critical path of backward: they only feed the gradient slab, so they run on a
+    second HIP stream and overlap the HBM-bound BN / elementwise passes of the layers below (fork = side waits on
+    main when the launch is issued; join = main waits on side before anything reads the slab, see join_side()).
+    STIL_WGRAD_STREAM=0 keeps everything on one stream; inside a hipGraph capture the launches stay inline."""
+
+    def __init__(self):
+        import os
+        self.enabled = os.environ.get("STIL_WGRAD_STREAM", "1") != "0"
+        self.streams = {}
+
+    def get(self, device):
+        st = self.streams.get(device)
+        if st is None:
+            st = self.streams[device] = torch.cuda.Stream(device)
+        return st
+
+
+_side = _SideStream()
+
+
+def join_side():
+    """Make the current stream wait for every side-stream launch issued so far."""
+    for st in _side.streams.values():
+        torch.cuda.current_stream(st.device).wait_stream(st)
+
+
+def side_stream(device):
+    """The side stream of `device`, or None when overlap is off / a hipGraph capture is running."""
+    if not _side.enabled or torch.cuda.is_current_stream_capturing() or _prof_active():
+        return None
+    return _side.get(device)
 
 
 def _grad_into(param: torch.Tensor, writer):
@@ -103,6 +138,28 @@ def wgrad_tn(dY, X, dW, M, N, K, *, ldy=None, ldx=None, geom=None, Kdst=None, ac
     L = lib()
     meta = (0, 2.0 * M * N * K, (M, N, K, geom[5], geom[7], 2)) if L._prof is not None else None
     L.wgrad_tn(_p(dY), _p(X), _p(dW), M, N, K, ldy, ldx, *geom, Kdst, accumulate, _p(w), nb, _stream(), meta=meta)
+
+
+def wgrad_param(param, dY, X, M, N, K, **kw):
+    """Weight gradient of a parameter.  Slab-backed parameters: "+=" into the slot on the side stream (returns None);
+    plain tensors: fresh gradient on the current stream (returned to autograd)."""
+    slot = getattr(param, "_gslot", None)
+    side = side_stream(dY.device) if slot is not None else None
+    if side is None:
+        return _grad_into(param, lambda dst, acc: wgrad_tn(dY, X, dst, M, N, K, accumulate=acc, **kw))
+    main = torch.cuda.current_stream()
+    if main != side:
+        side.wait_stream(main)
+        dY.record_stream(side)
+        X.record_stream(side)
+    with torch.cuda.stream(side):
+        wgrad_tn(dY, X, slot, M, N, K, accumulate=1, **kw)
+    param._stil_touched = True
+    return None
+
+
+def _prof_active():
+    return lib()._prof is not None  # per-entry-point timing brackets launches with events on ONE stream
 
 
 def colsum(X, out, M, N, *, ld=None, accumulate=0, scale=1.0):
@@ -163,7 +220,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt = transpose(weight)  # [K, N]
             dx = gemm_nt(g, wt, M, K, N).reshape(ctx.xshape)
-        dw = _grad_into(weight, lambda dst, acc: wgrad_tn(g, x2, dst, M, N, K, accumulate=acc)) if ctx.needs_input_grad[1] else None
+        dw = wgrad_param(weight, g, x2, M, N, K) if ctx.needs_input_grad[1] else None
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _grad_into(bias, lambda dst, acc: colsum(g, dst, M, N, accumulate=acc))
@@ -272,7 +329,7 @@ class ConvBnActFn(torch.autograd.Function):
         if is_stem:
             Kp = stem[3]
             Kreal = w.shape[1] * k * k
-            dw = _grad_into(w, lambda dst, a: wgrad_tn(dy, x, dst, M, Cout, Kp, Kdst=Kreal, accumulate=a))
+            dw = wgrad_param(w, dy, x, M, Cout, Kp, Kdst=Kreal)
         else:
             _, H, W_, Cin = x.shape
             if ctx.needs_input_grad[0]:
@@ -287,7 +344,7 @@ class ConvBnActFn(torch.autograd.Function):
                 else:
                     dx = strided_dgrad(dy, w, Nb, H, W_, Cin, OH, OW, Cout, k, stride, pad)
             gw = geom[:9]
-            dw = _grad_into(w, lambda dst, a: wgrad_tn(dy, x, dst, M, Cout, k * k * Cin, geom=gw, accumulate=a))
+            dw = wgrad_param(w, dy, x, M, Cout, k * k * Cin, geom=gw)
         return (dx, dw, (None if gslot is not None else dgamma), (None if bslot is not None else dbeta), None, None, None,
                 dres, None, None, None, None, None)
 
