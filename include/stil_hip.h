@@ -196,6 +196,21 @@ int stil_adam_step(float* params, const float* grads, float* exp_avg, float* exp
                    float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                    void* stream);
 
+/* ---- evaluation metrics (torchmetrics==0.11.0 as used by STiLModel.py:122-145, 360-363, 458-463, 529-545) ----
+ * hits_total: device int64[2] = {hits, samples}, accumulated (integer atomics: order-independent).
+ * metric_topk: target class within the k best scores of its row (k = 1: argmax's first-maximum rule).
+ * metric_binary: (prob > threshold) == (target == 1).
+ * auroc: exact area under the ROC curve (thresholds=None); K == 1: binary on scores[:,0] with positives target == 1;
+ *        K > 1: one-vs-rest per class and their unweighted mean (macro; a class without positives or negatives
+ *        scores 0).  Integer rank statistics per class (segmented radix sort), no float accumulation. */
+int stil_metric_topk(const float* scores, int ld, const long long* target, int N, int K, int k,
+                     long long* hits_total, void* stream);
+int stil_metric_binary(const float* probs, const long long* target, int N, float threshold, long long* hits_total,
+                       void* stream);
+size_t stil_auroc_workspace_bytes(int N, int K);
+int stil_auroc(const float* scores, int ld, const long long* target, int N, int K, float* auc_per_class, float* macro,
+               void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -902,6 +902,15 @@ class RowSoftmaxFn(torch.autograd.Function):
         return dz
 
 
+def softmax_rows(z):
+    """softmax over the last dim of a [rows, C] matrix (no autograd): metric probabilities, test_step scores."""
+    _chk(z)
+    R, C = z.shape
+    p = torch.empty_like(z)
+    lib().row_softmax_fwd(_p(z), _p(p), R, C, _stream())
+    return p
+
+
 class MatmulNNFn(torch.autograd.Function):
     """C = A @ B (A [M,K], B [K,N]) -- P @ V of the inter-sample attention."""
 

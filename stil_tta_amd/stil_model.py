@@ -18,6 +18,7 @@ import torch.nn as nn
 import torch.distributed as dist
 
 from . import ops
+from .metrics import AUROC, Accuracy
 from .flat import FlatState, StilAdam
 from .modules import DisCoAttentionBackbone, fuse_mi_masks, random_mi_masks
 from .ops import _p, _stream
@@ -39,7 +40,7 @@ _DEFAULTS = dict(
     start_epoch=35, rate_pseudo=0.9, use_ema=True, eman=True, ema_momentum=0.996, DA=False, repeat_ratio=1.0,
     batch_size=512, lr_eval=1e-4, weight_decay_eval=0.0, scheduler="anneal", warmup_epochs=10, max_epochs=500,
     checkpoint=None, pretrained_model="TIP", finetune_strategy="trainable", pretrain=False, logdir=None,
-    mi_dropout=True, seed=2022,
+    mi_dropout=True, seed=2022, train_metrics=True,
     tabular_encoder="transformer",  # "saint": the STiLModel_SAINT.py variant (also selected by algorithm_name == "STiL_SAINT")
 )
 
@@ -131,6 +132,7 @@ class STiLModel(_Base):
             self.DA_len = 256
             self.register_buffer("DA_queue", torch.zeros(self.DA_len, hp.num_classes))
             self.register_buffer("DA_ptr", torch.zeros(1, dtype=torch.long))
+        self.initialize_metrics(hp.batch_size, hp.batch_size)  # STiLModel.py:67,79: nclasses = hparams.batch_size
         self.best_val_score = 0
         self.flat: Optional[FlatState] = None
         self._rng_offset = 0
@@ -153,6 +155,29 @@ class STiLModel(_Base):
 
         def print(self, *a, **k):
             print(*a, **k)
+
+    def initialize_metrics(self, nclasses_train, nclasses_val):
+        """STiLModel.py:120-146 with the device-side metrics of metrics.py (torchmetrics call surface)."""
+        K = self.hp.num_classes
+        task = "binary" if K == 2 else "multiclass"
+        self.top1_acc_train = Accuracy("multiclass", nclasses_train, top_k=1)
+        self.top1_acc_val = Accuracy("multiclass", nclasses_val, top_k=1)
+        self.top5_acc_train = Accuracy("multiclass", nclasses_train, top_k=5)
+        self.top5_acc_val = Accuracy("multiclass", nclasses_val, top_k=5)
+        for n in ("train", "train_unlabelled", "train_pseudo", "val", "val_imaging", "val_tabular", "test"):
+            setattr(self, f"acc_{n}", Accuracy(task, K))
+            setattr(self, f"auc_{n}", AUROC(task, K))
+
+    def _metric_probs(self, logits):
+        """softmax(logits) for the metrics; column 1 for binary tasks (STiLModel.py:352-357, 450-457, 526-528)."""
+        p = ops.softmax_rows(logits.detach().contiguous())
+        return p[:, 1].contiguous() if self.hp.num_classes == 2 else p
+
+    def freeze(self):
+        """LightningModule.freeze(): no parameter requires grad, eval mode (trainers/evaluate.py:206, trainers/test.py:85)."""
+        for q in self.parameters():
+            q.requires_grad = False
+        return self.eval()
 
     def _load_tip_checkpoint(self, hp):
         """STiLModel_backbone.py:69-90,108-115: load encoder_imaging.* / encoder_tabular.* from a TIP checkpoint."""
@@ -316,6 +341,14 @@ class STiLModel(_Base):
                 dist.all_reduce(cs, op=dist.ReduceOp.SUM)  # ONE fused [K, Dp+1] collective instead of the reference's two
             lib().proto_add(_p(cs), _p(self.prototypes_sum), _p(self.prototypes_count_sum), K, hp.projection_dim, _stream())
 
+            if hp.train_metrics and not torch.cuda.is_current_stream_capturing():  # STiLModel.py:242, 359-362
+                prob_m = self._metric_probs(y_m)
+                y_u_dev = y_u.to(dev)
+                self.acc_train(prob_m[:B_l], y_l)
+                self.auc_train(prob_m[:B_l], y_l)
+                self.acc_train_unlabelled(prob_m[B_l:], y_u_dev)
+                self.auc_train_unlabelled(prob_m[B_l:], y_u_dev)
+
         lib().counter_inc(_p(self._rng_step), _stream())
         bs = B
         for name, v in (("CEloss", loss_ce), ("CEloss_unlabelled_m", loss_m_u), ("CEloss_unlabelled_i", loss_i_u),
@@ -335,6 +368,14 @@ class STiLModel(_Base):
     def training_epoch_end(self, _=None):
         """STiLModel.py:389-421: prototypes <- sum / count (every class needs a confident sample), zero accumulators."""
         K, Dp = self.hp.num_classes, self.hp.projection_dim
+        if self.hp.train_metrics and self.acc_train.counts is not None:  # STiLModel.py:393-405
+            vals = {}
+            for name, met in (("eval.train.acc", self.acc_train), ("eval.train.auc", self.auc_train),
+                              ("eval.train_unlabelled.acc", self.acc_train_unlabelled), ("eval.train_unlabelled.auc", self.auc_train_unlabelled)):
+                vals[name] = met.compute()
+                self.log(name, vals[name], on_epoch=True, on_step=False)
+                met.reset()
+            self.print(f"Epoch {self.current_epoch}: " + ", ".join(f"{k[5:]}: {float(v):.6f}" for k, v in vals.items()))
         bad = torch.zeros(1, dtype=torch.int32, device=self.prototypes.device)
         lib().proto_commit(_p(self.prototypes), _p(self.prototypes_sum), _p(self.prototypes_count_sum), _p(bad), K, Dp, _stream())
         assert int(bad.item()) == 0, "a class received no confident sample this epoch (STiLModel.py:412)"
@@ -346,29 +387,75 @@ class STiLModel(_Base):
     # ------------------------------------------------------------------ inference-side hooks
     @torch.no_grad()
     def validation_step(self, batch, _=None):
-        """STiLModel.py:424-474 (losses only; torchmetrics bookkeeping is left to the caller)."""
+        """STiLModel.py:424-474: losses, ITC retrieval top-1/top-5 (full batches only), task accuracy / AUROC of the
+        multimodal, imaging and tabular heads."""
         x, y = batch
         self.setup_device()
         dev = self.prototypes.device
+        y = y.to(dev)
         o = self.model.forward_all((x[0].to(dev, torch.float32).contiguous(), x[1].to(dev, torch.float32).contiguous()), train=False)
-        y_hat, _, _, si_e, si_m, ai, st_e, st_m, at, xc = o
+        y_hat, y_i_hat, y_t_hat, si_e, si_m, ai, st_e, st_m, at, xc = o
         _, fi, ft = self.project_3features(None, ai, at)
-        loss_itc, _ = ops.clip_loss(fi, ft, float(self.hp.temperature), float(self.hp.lambda_0))
+        loss_itc, itc_logits = ops.clip_loss(fi, ft, float(self.hp.temperature), float(self.hp.lambda_0))
+        if len(y) == self.hp.batch_size:  # STiLModel.py:437-438
+            labels = torch.arange(len(y), device=dev)
+            self.top1_acc_val(itc_logits, labels)
+            self.top5_acc_val(itc_logits, labels)
         ci, ei = self.CLUB_imaging.both(si_m, ai)
         ct, et = self.CLUB_tabular.both(st_m, at)
-        loss_ce = ops.CEHardFn.apply(y_hat.contiguous(), y.to(dev))
+        loss_ce = ops.CEHardFn.apply(y_hat.contiguous(), y)
         loss = self.hp.alpha * loss_ce + self.hp.beta * loss_itc + self.hp.gamma * (ci + ei + ct + et)
         for name, v in (("ITCloss", loss_itc), ("CLUBloss_imaging", ci), ("CLUBloss_imaging_est", ei), ("CLUBloss_tabular", ct),
                         ("CLUBloss_tabular_est", et), ("CEloss", loss_ce), ("loss", loss)):
             self.log(f"multimodal.val.{name}", v, on_epoch=True, on_step=False)
+        for head, logits in (("val", y_hat), ("val_imaging", y_i_hat), ("val_tabular", y_t_hat)):
+            pr = self._metric_probs(logits)
+            getattr(self, f"acc_{head}")(pr, y)
+            getattr(self, f"auc_{head}")(pr, y)
         return loss
+
+    def validation_epoch_end(self, _=None):
+        """STiLModel.py:476-515: epoch metrics, best_val_score (accuracy for DVM, AUROC otherwise), reset."""
+        try:
+            if self.trainer.sanity_checking:
+                return
+        except Exception:  # no Lightning trainer attached (the repo's own driver)
+            pass
+        if self.acc_val.counts is None:
+            return
+        vals = {}
+        for name, met in (("acc", self.acc_val), ("auc", self.auc_val), ("acc_imaging", self.acc_val_imaging),
+                          ("auc_imaging", self.auc_val_imaging), ("acc_tabular", self.acc_val_tabular), ("auc_tabular", self.auc_val_tabular)):
+            vals[name] = met.compute()
+            self.log(f"eval.val.{name}", vals[name], on_epoch=True, on_step=False)
+        if self.top1_acc_val.counts is not None:
+            self.log("multimodal.val.top1", self.top1_acc_val.compute(), on_epoch=True, on_step=False)
+            self.log("multimodal.val.top5", self.top5_acc_val.compute(), on_epoch=True, on_step=False)
+            self.top1_acc_val.reset()
+            self.top5_acc_val.reset()
+        self.print(f"Epoch {self.current_epoch}: " + ", ".join(f"val.{k}: {float(v):.6f}" for k, v in vals.items()))
+        score = float(vals["acc"] if self.hp.target == "dvm" else vals["auc"])
+        if score > self.best_val_score:
+            self.print(f"Best epoch: {self.current_epoch}")
+        self.best_val_score = max(self.best_val_score, score)
+        for met in (self.acc_val, self.auc_val, self.acc_val_imaging, self.auc_val_imaging, self.acc_val_tabular, self.auc_val_tabular):
+            met.reset()
 
     @torch.no_grad()
     def test_step(self, batch, _=None):
-        """STiLModel.py:517-533: returns softmax(y_hat) (column 1 for binary tasks)."""
+        """STiLModel.py:517-533: softmax(y_hat) (column 1 for binary tasks) into acc_test / auc_test; returns the scores."""
         x, y = batch
         self.setup_device()
         dev = self.prototypes.device
         y_hat = self.model.forward((x[0].to(dev, torch.float32).contiguous(), x[1].to(dev, torch.float32).contiguous()), train=False)[0]
-        p = torch.softmax(y_hat, dim=1)
-        return p[:, 1] if self.hp.num_classes == 2 else p
+        p = self._metric_probs(y_hat)
+        self.acc_test(p, y.to(dev))
+        self.auc_test(p, y.to(dev))
+        return p
+
+    def test_epoch_end(self, _=None):
+        """STiLModel.py:535-543."""
+        test_acc, test_auc = self.acc_test.compute(), self.auc_test.compute()
+        self.log("test.acc", test_acc)
+        self.log("test.auc", test_auc)
+        return {"test.acc": test_acc, "test.auc": test_auc}

@@ -67,3 +67,30 @@ def test_state_dict_layout_matches_reference_appendix_a():
     assert sum(1 for k in sd if k.startswith("ema.")) == 406
     n_train = sum(sd[k].numel() for k in O.trainable_keys(sd))
     assert abs(n_train - 46.72e6) < 0.02e6
+
+
+# ---------------------------------------------------------------- metrics oracle pinned against scikit-learn
+def test_metrics_oracle_against_sklearn():
+    import numpy as np
+    from sklearn.metrics import roc_auc_score, top_k_accuracy_score
+    from oracle import metrics_oracle as MO
+    rng = np.random.default_rng(0)
+    # binary, with heavy ties
+    s = np.round(rng.random(500), 1).astype(np.float32)
+    y = rng.integers(0, 2, 500)
+    assert abs(MO.binary_auroc(s, y == 1) - roc_auc_score(y, s)) < 1e-12
+    assert MO.binary_accuracy(s, y) == float(((s > 0.5) == (y == 1)).mean())
+    # multiclass one-vs-rest macro (every class present), softmax rows
+    K = 7
+    z = rng.normal(size=(400, K)).astype(np.float32)
+    p = np.exp(z) / np.exp(z).sum(1, keepdims=True)
+    yk = np.concatenate([np.arange(K), rng.integers(0, K, 400 - K)])
+    macro, per = MO.multiclass_auroc(p, yk)
+    assert abs(macro - roc_auc_score(yk, p.astype(np.float64) / p.astype(np.float64).sum(1, keepdims=True), multi_class="ovr", average="macro")) < 1e-6
+    for c in range(K):
+        assert abs(per[c] - roc_auc_score(yk == c, p[:, c])) < 1e-12
+    # top-k (no ties in continuous scores)
+    for k in (1, 5):
+        assert abs(MO.topk_accuracy(z, yk, k) - top_k_accuracy_score(yk, z, k=k, labels=np.arange(K))) < 1e-12
+    # degenerate class: no positives -> 0 (torchmetrics 0.11.0 rule, unpinned)
+    assert MO.binary_auroc(s, np.zeros(500, bool)) == 0.0
