@@ -1,0 +1,103 @@
+"""The Lightning-free fit / test loops (stil_tta_amd/fit.py) end to end on a tiny synthetic task: checkpoint-on-best,
+Lightning-shaped checkpoint contents, reload into a fresh module, resume, early stopping."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+FL = [3, 4] + [1] * 3
+
+
+def _data(n, seed, K=3):
+    """class-dependent images and columns so that a few steps already move the validation accuracy"""
+    g = torch.Generator().manual_seed(seed)
+    y = torch.randint(0, K, (n,), generator=g)
+    img = torch.rand(n, 3, 64, 64, generator=g) * 0.2 + (y.float() / K)[:, None, None, None]
+    tab = torch.cat([torch.randint(0, 3, (n, 1), generator=g).float(), (y % 4).float()[:, None], torch.randn(n, 3, generator=g) + y.float()[:, None]], 1)
+    return img, tab, y
+
+
+class _Pairs:
+    """DataLoader stand-in yielding the reference's per-part batch tuple."""
+
+    def __init__(self, img, tab, y, bs, labelled):
+        self.img, self.tab, self.y, self.bs, self.lab = img, tab, y, bs, labelled
+
+    def __len__(self):
+        return len(self.y) // self.bs
+
+    def __iter__(self):
+        for i in range(len(self)):
+            s = slice(i * self.bs, (i + 1) * self.bs)
+            n = self.bs
+            yield ([torch.zeros(n), self.img[s]], [self.tab[s], self.tab[s]], self.y[s], self.img[s], torch.full((n,), self.lab, dtype=torch.bool))
+
+
+class _Val:
+    def __init__(self, img, tab, y, bs):
+        self.img, self.tab, self.y, self.bs = img, tab, y, bs
+
+    def __len__(self):
+        return (len(self.y) + self.bs - 1) // self.bs
+
+    def __iter__(self):
+        for i in range(len(self)):
+            s = slice(i * self.bs, (i + 1) * self.bs)
+            yield ((self.img[s], self.tab[s]), self.y[s])
+
+
+def _model(**over):
+    from stil_tta_amd import STiLModel
+    torch.manual_seed(0)
+    hp = dict(model="resnet18", embedding_dim=512, field_lengths=FL, num_classes=3, batch_size=16, target="dvm", start_epoch=0, th1=0.5,
+              lr_eval=1e-3, warmup_epochs=2, max_epochs=6, mi_dropout=False)
+    hp.update(over)
+    return STiLModel(hp)
+
+
+def test_fit_checkpoint_reload_resume_and_test(tmp_path):
+    from stil_tta_amd import fit as F
+    l_bs, u_bs = F.split_batch_size(16, 7)
+    li, lt, ly = _data(8, 1)
+    ui, ut, uy = _data(56, 2)
+    vi, vt, vy = _data(40, 3)
+    loaders = {"l": _Pairs(li, lt, ly, l_bs, True), "u": _Pairs(ui, ut, uy, u_bs, False)}
+    val = _Val(vi, vt, vy, 16)
+    m = _model()
+    m.setup_device("cuda")
+    m.prototypes.copy_(torch.nn.functional.normalize(torch.randn(3, 128, generator=torch.Generator().manual_seed(5))).cuda())
+    out = F.fit(m, loaders, val, max_epochs=4, eval_metric="acc", logdir=str(tmp_path), verbose=False)
+    assert out["stopped"] == "max_epochs" and out["epochs_run"] == 4 and out["global_step"] == 4 * 4
+    assert os.path.exists(out["checkpoint"]) and out["checkpoint"].endswith("checkpoint_best_acc.ckpt")
+    assert abs(out["best_score"] - m.best_val_score) < 1e-7
+    ck = torch.load(out["checkpoint"], map_location="cpu", weights_only=False)
+    assert set(ck) >= {"epoch", "global_step", "state_dict", "hyper_parameters", "optimizer_states", "lr_schedulers", "pytorch-lightning_version"}
+    assert ck["epoch"] == out["best_epoch"] and len(ck["optimizer_states"][0]["param_groups"]) == 6  # STiLModel.py:563-570
+    assert any(k.startswith("ema.") for k in ck["state_dict"]) and "prototypes" in ck["state_dict"]
+    # a fresh module + the checkpoint reproduces the best validation score exactly
+    m2 = _model()
+    m2.setup_device("cuda")
+    F.load_checkpoint(out["checkpoint"], m2)
+    got = F.validate(m2, val)
+    assert abs(got["eval.val.acc"] - out["best_score"]) < 1e-7
+    res = F.test(m2, val, ckpt_path=out["checkpoint"])
+    assert abs(res["test.acc"] - out["best_score"]) < 1e-7 and 0.0 <= res["test.auc"] <= 1.0
+    # resume continues the epoch / step counters and restores Adam's moments
+    m3 = _model()
+    out3 = F.fit(m3, loaders, val, max_epochs=ck["epoch"] + 2, logdir=str(tmp_path / "resumed"), resume_from=out["checkpoint"], verbose=False)
+    assert out3["epochs_run"] == 1 and out3["global_step"] == ck["global_step"] + 4
+    st = ck["optimizer_states"][0]["state"]
+    steps = [float(v["step"]) for v in st.values()]  # heads that only feed the pseudo-label losses start one epoch later
+    assert len(st) > 100 and max(steps) == ck["global_step"] and min(steps) >= ck["global_step"] - 4
+
+
+def test_early_stopping_ends_fit(tmp_path):
+    from stil_tta_amd import fit as F
+    li, lt, ly = _data(4, 1)
+    ui, ut, uy = _data(28, 2)
+    vi, vt, vy = _data(16, 3)
+    m = _model(batch_size=16, lr_eval=0.0, scheduler="none")  # nothing can improve: stops after `patience` checks
+    loaders = {"l": _Pairs(li, lt, ly, 2, True), "u": _Pairs(ui, ut, uy, 14, False)}
+    out = F.fit(m, loaders, _Val(vi, vt, vy, 16), max_epochs=50, val_check_interval=50.0, logdir=None, verbose=False)  # patience int(100/50) = 2
+    assert out["stopped"] == "early_stopping" and out["epochs_run"] == 3

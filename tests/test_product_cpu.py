@@ -119,3 +119,32 @@ def test_data_parallel_exchange_world2_gloo():
     for p in ps:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+# ---------------------------------------------------------------- fit-loop host logic (stil_tta_amd/fit.py)
+def test_fit_host_helpers():
+    from stil_tta_amd import fit as F
+    assert F.split_batch_size(512, 7) == (64, 448) and F.split_batch_size(64, 7) == (8, 56)  # trainers/evaluate.py:84-85
+    assert F.repeat_ratio(90000, 1000, 7) == 11 and F.repeat_ratio(100, 1000, 7) == 1       # trainers/evaluate.py:83
+
+    class Loader:  # reshuffles on every restart, like DataLoader(shuffle=True)
+        def __init__(self, n):
+            self.n, self.starts = n, 0
+
+        def __len__(self):
+            return self.n
+
+        def __iter__(self):
+            self.starts += 1
+            return iter([(self.starts, i) for i in range(self.n)])
+
+    l, u = Loader(2), Loader(5)
+    seen = list(F.max_size_cycle({"l": l, "u": u}))
+    assert len(seen) == 5 and [b["u"][1] for b in seen] == [0, 1, 2, 3, 4]
+    assert [b["l"] for b in seen] == [(1, 0), (1, 1), (2, 0), (2, 1), (3, 0)]  # the short loader is restarted, not padded
+
+    es = F.EarlyStopping(min_delta=1e-4, patience=3)
+    assert [es.should_stop(v) for v in (0.5, 0.50005, 0.4, 0.6, 0.6, 0.6, 0.60009)] == [False, False, False, False, False, False, True]
+    bc = F.BestCheckpoint("eval.val.acc", "/tmp/x", "checkpoint_best_acc")
+    assert bc.path == "/tmp/x/checkpoint_best_acc.ckpt"
+    assert [bc.improved(v, e) for e, v in enumerate((0.1, 0.1, 0.3, 0.2))] == [True, False, True, False] and bc.best_epoch == 2
