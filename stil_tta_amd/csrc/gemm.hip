@@ -282,9 +282,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p) {
   float* Xs = lds + 2 * BMr * BN;
 
   const int nbk = (p.K + BKo - 1) / BKo, nbn = (p.N + BN - 1) / BN;
-  const int wg = xcd_remap(blockIdx.x, nbn * nbk);
+  // 1-D grid over (m-slab z, tile): an XCD gets a contiguous range, so the tiles that re-read one slab of dY / X share an L2
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int z = lin / (nbn * nbk), wg = lin - z * (nbn * nbk);
   const int tn = wg / nbk, tk = wg - tn * nbk;
-  const int z = blockIdx.z;
   const int m_begin = z * p.m_per_split;
   const int m_end = min(p.M, m_begin + p.m_per_split);
   const int tid = threadIdx.x;
@@ -534,10 +535,15 @@ extern "C" int stil_set_wgrad_variant(int v) {
   g_tn_variant = v;
   return STIL_OK;
 }
-// measured (tests/tools/gemm_bench.py): 64x64 tiles win for N <= 256 (more blocks, fewer M-splits, less slab traffic)
-static inline int tn_variant(int N) { return g_tn_variant ? g_tn_variant : (N <= 256 ? 11 : 22); }
+// measured in situ (bench.py --breakdown, cold caches): 64x64 tiles win for N <= 256 (more blocks, fewer M-splits) except the
+// 1x1 convolutions with 128..256 outputs and K in 256..1024, where 128x128 halves the operand re-reads
+static inline int tn_variant(int N, int K) {
+  if (g_tn_variant) return g_tn_variant;
+  if (N > 256) return 22;
+  return (N >= 128 && K >= 256 && K <= 1024) ? 22 : 11;
+}
 static int wgrad_splits(int M, int N, int K) {
-  const int tv = tn_variant(N);
+  const int tv = tn_variant(N, K);
   int tiles = tv == 11 ? cdiv(N, 64) * cdiv(K, 64) : cdiv(N, N <= 64 ? 64 : 128) * cdiv(K, 128);
   int want = cdiv(tv == 11 ? 2304 : 768, tiles);
   int maxs = M / 256 > 0 ? M / 256 : 1;
@@ -571,16 +577,16 @@ extern "C" int stil_wgrad_tn(const float* dY, const float* X, float* dW, int M, 
   p.vecX = is_vec(X, ldx) && (srcC % 4 == 0);
   hipStream_t s = (hipStream_t)stream;
   const bool vec = p.vecY && p.vecX && (N % 4 == 0) && (K % 4 == 0);
-  if (tn_variant(N) == 11) {
-    dim3 grid(cdiv(N, 64) * cdiv(K, 64), 1, splits);
+  if (tn_variant(N, K) == 11) {
+    dim3 grid(cdiv(N, 64) * cdiv(K, 64) * splits);
     if (vec) hipLaunchKernelGGL((gemm_tn_kernel<1, 1, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((gemm_tn_kernel<1, 1, false>), grid, dim3(256), 0, s, p);
   } else if (N <= 64) {
-    dim3 grid(cdiv(N, 64) * cdiv(K, 128), 1, splits);
+    dim3 grid(cdiv(N, 64) * cdiv(K, 128) * splits);
     if (vec) hipLaunchKernelGGL((gemm_tn_kernel<1, 2, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((gemm_tn_kernel<1, 2, false>), grid, dim3(256), 0, s, p);
   } else {
-    dim3 grid(cdiv(N, 128) * cdiv(K, 128), 1, splits);
+    dim3 grid(cdiv(N, 128) * cdiv(K, 128) * splits);
     if (vec) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, false>), grid, dim3(256), 0, s, p);
   }
