@@ -20,13 +20,16 @@ from . import ops
 
 
 # ------------------------------------------------------------------------------------------ ResNet
-def _conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool, train: bool, resid=None, stem=None):
+def _conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool, train: bool, resid=None, stem=None, passthrough=False):
+    """passthrough (first conv of a residual block): -> (out, alias of x) so the identity branch's gradient is folded
+    into this conv's input-gradient GEMM (ops.ConvBnActFn)."""
     k, stride, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
     if train:
         return ops.ConvBnActFn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                     bn.num_batches_tracked, resid, k, stride, pad, relu, stem)
-    return ops.conv_bn_eval(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, resid, k, stride, pad,
-                            relu, stem)
+                                     bn.num_batches_tracked, resid, k, stride, pad, relu, stem, passthrough)
+    out = ops.conv_bn_eval(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, resid, k, stride, pad,
+                           relu, stem)
+    return (out, x) if passthrough else out
 
 
 class Bottleneck(nn.Module):  # models/resnets.py:91-132
@@ -43,11 +46,10 @@ class Bottleneck(nn.Module):  # models/resnets.py:91-132
         self.downsample = downsample
 
     def run(self, x, train):
-        identity = x
-        out = _conv_bn(x, self.conv1, self.bn1, True, train)
+        out, identity = _conv_bn(x, self.conv1, self.bn1, True, train, passthrough=True)
         out = _conv_bn(out, self.conv2, self.bn2, True, train)
         if self.downsample is not None:
-            identity = _conv_bn(x, self.downsample[0], self.downsample[1], False, train)
+            identity = _conv_bn(identity, self.downsample[0], self.downsample[1], False, train)
         Nb, H, W, C = identity.shape
         return _conv_bn(out, self.conv3, self.bn3, True, train, resid=identity.reshape(Nb * H * W, C))
 
@@ -64,10 +66,9 @@ class BasicBlock(nn.Module):  # models/resnets.py:50-88
         self.downsample = downsample
 
     def run(self, x, train):
-        identity = x
-        out = _conv_bn(x, self.conv1, self.bn1, True, train)
+        out, identity = _conv_bn(x, self.conv1, self.bn1, True, train, passthrough=True)
         if self.downsample is not None:
-            identity = _conv_bn(x, self.downsample[0], self.downsample[1], False, train)
+            identity = _conv_bn(identity, self.downsample[0], self.downsample[1], False, train)
         Nb, H, W, C = identity.shape
         return _conv_bn(out, self.conv2, self.bn2, True, train, resid=identity.reshape(Nb * H * W, C))
 

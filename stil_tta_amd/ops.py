@@ -267,8 +267,12 @@ class ConvBnActFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, rmean, rvar, nbt, resid, k, stride, pad, relu, stem):
+    def forward(ctx, x, w, gamma, beta, rmean, rvar, nbt, resid, k, stride, pad, relu, stem, passthrough=False):
+        """passthrough: also return x itself as a second output.  A residual block routes its identity branch through
+        that alias, so the branch's gradient arrives HERE and is added inside the input-gradient GEMM's epilogue
+        instead of by a separate accumulation kernel of the autograd engine."""
         _chk(x, w, gamma, beta, resid)
+        ctx.set_materialize_grads(False)
         Cout = w.shape[0]
         dev = x.device
         if stem is not None:  # x is col [M, Kp]; stem = (N, OH, OW, Kp, wpad)
@@ -297,10 +301,12 @@ class ConvBnActFn(torch.autograd.Function):
                            1 if relu else 0, 1e-5, 0.1, _p(ws), nb, _stream())
         ctx.save_for_backward(x, w, gamma, beta, y, z, stats)
         ctx.cfg = (k, stride, pad, relu, stem is not None, resid is not None, geom, (Nb, OH, OW), stem)
+        if passthrough:
+            return z.view(Nb, OH, OW, Cout), x
         return z.view(Nb, OH, OW, Cout)
 
     @staticmethod
-    def backward(ctx, gz):
+    def backward(ctx, gz, gx_alias=None):
         x, w, gamma, beta, y, z, stats = ctx.saved_tensors
         k, stride, pad, relu, is_stem, has_res, geom, (Nb, OH, OW), stem = ctx.cfg
         dev = x.device
@@ -333,20 +339,25 @@ class ConvBnActFn(torch.autograd.Function):
         else:
             _, H, W_, Cin = x.shape
             if ctx.needs_input_grad[0]:
+                ga = None if gx_alias is None else gx_alias.contiguous().view(Nb * H * W_, Cin)
                 if k == 1 and stride == 1:
                     wd = transpose(w.reshape(Cout, Cin))  # [Cin, Cout]
-                    dx = gemm_nt(dy, wd, M, Cin, Cout).view(Nb, H, W_, Cin)
+                    dx = gemm_nt(dy, wd, M, Cin, Cout, resid=ga).view(Nb, H, W_, Cin)
                 elif stride == 1:
                     wd = torch.empty((Cin, k * k * Cout), dtype=torch.float32, device=dev)
                     lib().conv_weight_layout(_p(w), None, _p(wd), Cout, Cin, k, k, _stream())
                     g2 = (OH, OW, Cout, H, W_, k, k, stride, pad, 1)
-                    dx = gemm_nt(dy, wd, Nb * H * W_, Cin, k * k * Cout, geom=g2).view(Nb, H, W_, Cin)
+                    dx = gemm_nt(dy, wd, Nb * H * W_, Cin, k * k * Cout, geom=g2, resid=ga).view(Nb, H, W_, Cin)
                 else:
                     dx = strided_dgrad(dy, w, Nb, H, W_, Cin, OH, OW, Cout, k, stride, pad)
+                    if ga is not None:
+                        axpby(dx.view(-1), ga.view(-1), 1.0, 1.0, out=dx.view(-1))
+            elif gx_alias is not None:
+                dx = gx_alias
             gw = geom[:9]
             dw = wgrad_param(w, dy, x, M, Cout, k * k * Cin, geom=gw)
         return (dx, dw, (None if gslot is not None else dgamma), (None if bslot is not None else dbeta), None, None, None,
-                dres, None, None, None, None, None)
+                dres, None, None, None, None, None, None)
 
 
 def strided_dgrad(dy, w, Nb, H, W_, Cin, OH, OW, Cout, k, stride, pad):
