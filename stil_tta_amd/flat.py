@@ -92,6 +92,23 @@ class FlatState:
             torch._foreach_copy_(self.t_counters, self.s_counters)
 
     @torch.no_grad()
+    def ema_update_params(self, momentum: float):
+        """Parameters only (the BN running buffers follow layer by layer, see modules.TeacherPipe)."""
+        lib().ema_update(_p(self.ema), _p(self.params), self.n_backbone_params, float(momentum), _stream())
+
+    @torch.no_grad()
+    def ema_update_range(self, offset: int, n: int, momentum: float):
+        """EMA of ema[offset:offset+n] (floats; both multiples of the 1024-float tensor alignment)."""
+        assert offset % ALIGN == 0 and n % ALIGN == 0 and 0 <= offset and offset + n <= self.n_backbone_state
+        vp = ctypes.c_void_p
+        lib().ema_update(vp(self.ema.data_ptr() + 4 * offset), vp(self.params.data_ptr() + 4 * offset), n, float(momentum), _stream())
+
+    @torch.no_grad()
+    def copy_counters(self, eman: bool):
+        if eman and self.s_counters:
+            torch._foreach_copy_(self.t_counters, self.s_counters)
+
+    @torch.no_grad()
     def copy_student_to_teacher(self):
         self.ema.copy_(self.params[: self.n_backbone_state])
         if self.s_counters:

@@ -20,13 +20,58 @@ from . import ops
 
 
 # ------------------------------------------------------------------------------------------ ResNet
+class TeacherPipe:
+    """Layer-wise hand-over between the student (main stream) and the EMA teacher (side stream).  While `recording`,
+    every training-mode conv+BN publishes an event after its running statistics are updated; while `replaying`, the
+    k-th eval-mode conv+BN first waits for the k-th event, then (eman) averages its own running_mean / running_var
+    from the student's -- the per-layer slice of momentum_update_ema (STiLModel.py:154-168) -- and only then reads them."""
+
+    def __init__(self, flat, momentum: float, eman: bool):
+        self.flat, self.momentum, self.eman = flat, float(momentum), eman
+        self.events = []
+        self.i = 0
+        self.recording = True
+        self.start = torch.cuda.Event()
+
+    def replay(self):
+        self.recording, self.i = False, 0
+
+    def published(self):
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events.append(ev)
+
+    def before_teacher_bn(self, bn: nn.BatchNorm2d):
+        torch.cuda.current_stream().wait_event(self.events[self.i])
+        self.i += 1
+        if self.eman:
+            f = self.flat
+            off = (bn.running_mean.data_ptr() - f.ema.data_ptr()) // 4
+            n = (bn.running_var.data_ptr() - bn.running_mean.data_ptr()) // 4  # = padded length of one buffer
+            f.ema_update_range(off, 2 * n, self.momentum)
+
+
+_PIPE: Optional[TeacherPipe] = None
+
+
+def set_teacher_pipe(pipe: Optional[TeacherPipe]):
+    global _PIPE
+    _PIPE = pipe
+
+
 def _conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool, train: bool, resid=None, stem=None, passthrough=False):
     """passthrough (first conv of a residual block): -> (out, alias of x) so the identity branch's gradient is folded
     into this conv's input-gradient GEMM (ops.ConvBnActFn)."""
     k, stride, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+    pipe = _PIPE
     if train:
-        return ops.ConvBnActFn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                     bn.num_batches_tracked, resid, k, stride, pad, relu, stem, passthrough)
+        out = ops.ConvBnActFn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                    bn.num_batches_tracked, resid, k, stride, pad, relu, stem, passthrough)
+        if pipe is not None and pipe.recording:
+            pipe.published()
+        return out
+    if pipe is not None and not pipe.recording:
+        pipe.before_teacher_bn(bn)
     out = ops.conv_bn_eval(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, resid, k, stride, pad,
                            relu, stem)
     return (out, x) if passthrough else out

@@ -20,7 +20,7 @@ import torch.distributed as dist
 from . import ops
 from .metrics import AUROC, Accuracy
 from .flat import FlatState, StilAdam
-from .modules import DisCoAttentionBackbone, fuse_mi_masks, random_mi_masks
+from .modules import DisCoAttentionBackbone, TeacherPipe, fuse_mi_masks, random_mi_masks, set_teacher_pipe
 from .ops import _p, _stream
 from ._lib import lib
 
@@ -293,12 +293,40 @@ class STiLModel(_Base):
         self._rng_offset = 0  # call-site offsets inside this step; the step itself is counted on the device (_rng_step)
 
         masks = self._mi_masks(B, mi_masks)
-        s = self.model.forward_all((x_img, x_tab), train=True, mi_masks=masks, cache=cache)
+        # The EMA teacher runs beside the student on the side stream, one BN layer behind it: parameters are averaged up
+        # front (the forward pass does not change them); each teacher BN waits for the student's statistics update of
+        # the same layer, averages its two running buffers and goes on (modules.TeacherPipe) -- same kernels, same
+        # operands, same results as "student, then momentum_update_ema, then teacher" (STiLModel.py:248-257).
+        side = ops.side_stream(dev) if self.use_ema else None
+        pipe = None
+        if side is not None:
+            with torch.no_grad():
+                self.flat.ema_update_params(hp.ema_momentum)
+            pipe = TeacherPipe(self.flat, hp.ema_momentum, bool(hp.eman))
+            pipe.start.record()
+            set_teacher_pipe(pipe)
+        try:
+            s = self.model.forward_all((x_img, x_tab), train=True, mi_masks=masks, cache=cache)
+            if pipe is not None:
+                with torch.no_grad(), torch.cuda.stream(side):
+                    side.wait_event(pipe.start)
+                    pipe.replay()
+                    t = self.ema.forward_all((x_img, x_tab), train=False, cache=cache)
+                    feat_m_e, _, _ = self.project_3features(torch.cat((t[3], t[9], t[6]), dim=1))
+                main = torch.cuda.current_stream()
+                main.wait_stream(side)
+                for tt in (*t, feat_m_e):
+                    tt.record_stream(main)
+                self.flat.copy_counters(bool(hp.eman))
+        finally:
+            set_teacher_pipe(None)
         y_m, y_i, y_t, si_e, si_m, ai, st_e, st_m, at, xc = s
         feat_m, feat_i, feat_t = self.project_3features(torch.cat((si_e, xc, st_e), dim=1), ai, at)
 
         with torch.no_grad():
-            if self.use_ema:
+            if pipe is not None:
+                ym_e, yi_e, yt_e = t[0], t[1], t[2]
+            elif self.use_ema:
                 self.flat.ema_update(hp.ema_momentum, bool(hp.eman))
                 t = self.ema.forward_all((x_img, x_tab), train=False, cache=cache)
                 feat_m_e, _, _ = self.project_3features(torch.cat((t[3], t[9], t[6]), dim=1))

@@ -290,3 +290,31 @@ def test_graphed_step_replays_the_eager_step_bit_for_bit():
     assert torch.equal(me.flat.params, mg.flat.params) and torch.equal(me.flat.ema, mg.flat.ema)
     assert torch.equal(me.prototypes_sum, mg.prototypes_sum)
     assert any(not torch.equal(masks_seen[0], m_) for m_ in masks_seen[1:]), "replays must draw fresh random masks"
+
+
+def test_side_stream_pipeline_is_bit_exact():
+    """Teacher beside the student (layer-wise BN hand-over) + weight gradients on the side stream produce exactly the bits
+    of the single-stream order "student, momentum_update_ema, teacher, backward" (same kernels, same operands)."""
+    from stil_tta_amd import STiLModel, ops
+    from stil_tta_amd.driver import synthetic_batch, train_step
+    from stil_tta_amd.flat import StilAdam
+    fl = [3, 4] + [1] * 3
+    outs = []
+    for enabled in (False, True):
+        ops._side.enabled = enabled
+        try:
+            torch.manual_seed(0)
+            m = STiLModel(dict(model="resnet18", embedding_dim=512, field_lengths=fl, num_classes=5, start_epoch=0, batch_size=16, th1=0.3))
+            m.setup_device("cuda"); m.train(); m.current_epoch = 1
+            m.prototypes.copy_(torch.nn.functional.normalize(torch.randn(5, 128, generator=torch.Generator().manual_seed(1))).cuda())
+            opt = StilAdam(m.flat, lr=1e-3)
+            batch = synthetic_batch(fl, 5, 16, 64, seed=3, device="cuda")
+            losses = [float(train_step(m, opt, batch)) for _ in range(3)]
+            torch.cuda.synchronize()
+            outs.append((losses, m.flat.params.clone(), m.flat.ema.clone(), m.flat.grads.clone(), m.last["y_hat_m_e"].clone(), m.prototypes_sum.clone()))
+        finally:
+            ops._side.enabled = True
+    a, b = outs
+    assert a[0] == b[0]
+    for x, y in zip(a[1:], b[1:]):
+        assert torch.equal(x, y)
