@@ -21,20 +21,17 @@ from . import ops
 
 # ------------------------------------------------------------------------------------------ ResNet
 class TeacherPipe:
-    """Layer-wise hand-over between the student (main stream) and the EMA teacher (side stream).  While `recording`,
-    every training-mode conv+BN publishes an event after its running statistics are updated; while `replaying`, the
-    k-th eval-mode conv+BN first waits for the k-th event, then (eman) averages its own running_mean / running_var
-    from the student's -- the per-layer slice of momentum_update_ema (STiLModel.py:154-168) -- and only then reads them."""
+    """Layer-wise hand-over between the student (main stream) and the EMA teacher (side stream).  Every training-mode
+    conv+BN publishes an event after its running statistics are updated; the k-th eval-mode conv+BN first waits for the
+    k-th event, then (eman) averages its own running_mean / running_var from the student's -- the per-layer slice of
+    momentum_update_ema (STiLModel.py:154-168) -- and only then reads them.  ResNet.run_pair issues the two networks
+    block by block, so the teacher trails the student by one block on the device as well as on the host."""
 
     def __init__(self, flat, momentum: float, eman: bool):
         self.flat, self.momentum, self.eman = flat, float(momentum), eman
         self.events = []
         self.i = 0
-        self.recording = True
         self.start = torch.cuda.Event()
-
-    def replay(self):
-        self.recording, self.i = False, 0
 
     def published(self):
         ev = torch.cuda.Event()
@@ -67,10 +64,10 @@ def _conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool, train: bool, re
     if train:
         out = ops.ConvBnActFn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                     bn.num_batches_tracked, resid, k, stride, pad, relu, stem, passthrough)
-        if pipe is not None and pipe.recording:
+        if pipe is not None:
             pipe.published()
         return out
-    if pipe is not None and not pipe.recording:
+    if pipe is not None:
         pipe.before_teacher_bn(bn)
     out = ops.conv_bn_eval(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, resid, k, stride, pad,
                            relu, stem)
@@ -152,7 +149,7 @@ class ResNet(nn.Module):
             layers.append(block(self.inplanes, planes))
         return nn.Sequential(*layers)
 
-    def run(self, x_nchw, train: bool, cache: Optional[dict] = None):
+    def _stem(self, x_nchw, train: bool, cache: Optional[dict]):
         # stem: im2col is shared between the student and the teacher pass (same input batch)
         if cache is not None and "stem_col" in cache:
             col, meta = cache["stem_col"]
@@ -162,12 +159,31 @@ class ResNet(nn.Module):
                 cache["stem_col"] = (col, meta)
         wpad = ops.pad_stem_weight(self.conv1.weight, meta[3])
         x = _conv_bn(col, self.conv1, self.bn1, True, train, stem=(*meta, wpad))
-        x = ops.MaxPoolFn.apply(x)
-        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
-            for blk in layer:
-                x = blk.run(x, train)
+        return ops.MaxPoolFn.apply(x)
+
+    def _blocks(self):
+        return [blk for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for blk in layer]
+
+    def run(self, x_nchw, train: bool, cache: Optional[dict] = None):
+        x = self._stem(x_nchw, train, cache)
+        for blk in self._blocks():
+            x = blk.run(x, train)
         Nb, H, W, C = x.shape
         return x.reshape(Nb, H * W, C)
+
+    def run_pair(self, teacher: "ResNet", x_nchw, cache: dict, side: torch.cuda.Stream):
+        """Student (self, training mode, current stream) and EMA teacher (eval mode, no grad, `side`) issued block by
+        block; needs an active TeacherPipe (set_teacher_pipe) for the per-BN hand-over.  -> (student tokens, teacher tokens)"""
+        def on_side(fn, *a):
+            with torch.no_grad(), torch.cuda.stream(side):
+                return fn(*a)
+        xs = self._stem(x_nchw, True, cache)
+        xt = on_side(teacher._stem, x_nchw, False, cache)
+        for bs, bt in zip(self._blocks(), teacher._blocks()):
+            xs = bs.run(xs, True)
+            xt = on_side(bt.run, xt, False)
+        Nb, H, W, C = xs.shape
+        return xs.reshape(Nb, H * W, C), on_side(lambda t: t.reshape(Nb, H * W, C), xt)
 
 
 # ------------------------------------------------------------------------------------------ tabular transformer
@@ -366,11 +382,13 @@ class DisCoAttentionBackbone(nn.Module):
         self.classifier_imaging = nn.Linear(C * 2, hp.num_classes)
         self.classifier_tabular = nn.Linear(C * 2, hp.num_classes)
 
-    def forward_all(self, x, train: Optional[bool] = None, mi_masks=None, cache=None):
-        """-> (out_m, out_i, out_t, x_si_enhance, mean(x_si), x_ai, x_st_enhance, mean(x_st), x_at, x_c)"""
+    def forward_all(self, x, train: Optional[bool] = None, mi_masks=None, cache=None, x_i=None):
+        """-> (out_m, out_i, out_t, x_si_enhance, mean(x_si), x_ai, x_st_enhance, mean(x_st), x_at, x_c);
+        x_i: image tokens when the caller already ran the image encoder (ResNet.run_pair)."""
         train = self.training if train is None else train
         x_img, x_tab = x[0], x[1]
-        x_i = self.encoder_imaging.run(x_img, train, cache)           # [B, Ni, pooled]
+        if x_i is None:
+            x_i = self.encoder_imaging.run(x_img, train, cache)       # [B, Ni, pooled]
         x_t = self.encoder_tabular.run(x_tab)                         # [B, Nt+1, Dt]
         x_si = self.projection_si.run(x_i)
         x_ai = self.projection_ai.run(ops.tokmean(x_i))

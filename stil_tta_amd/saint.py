@@ -186,10 +186,11 @@ class SaintBackbone(nn.Module):
         xr = _prenorm_res(xr, f2, lambda xn: _ff(f2.fn.fn, xn, mk("ff_row"), self.ff_drop))
         return xr.reshape(B, n, d)
 
-    def forward_all(self, x, train: Optional[bool] = None, mi_masks=None, cache=None):
+    def forward_all(self, x, train: Optional[bool] = None, mi_masks=None, cache=None, x_i=None):
         train = self.training if train is None else train
         x_img, x_tab = x[0], x[1]
-        x_i = self.encoder_imaging.run(x_img, train, cache)
+        if x_i is None:
+            x_i = self.encoder_imaging.run(x_img, train, cache)
         sm = None if (mi_masks is None or not train) else mi_masks.get("saint")
         x_t = self.forward_tabular(x_tab, sm)
         x_si = self.projection_si.run(x_i)

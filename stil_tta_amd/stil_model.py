@@ -306,14 +306,16 @@ class STiLModel(_Base):
             pipe.start.record()
             set_teacher_pipe(pipe)
         try:
-            s = self.model.forward_all((x_img, x_tab), train=True, mi_masks=masks, cache=cache)
-            if pipe is not None:
-                with torch.no_grad(), torch.cuda.stream(side):
-                    side.wait_event(pipe.start)
-                    pipe.replay()
-                    t = self.ema.forward_all((x_img, x_tab), train=False, cache=cache)
-                    feat_m_e, _, _ = self.project_3features(torch.cat((t[3], t[9], t[6]), dim=1))
+            if pipe is None:
+                s = self.model.forward_all((x_img, x_tab), train=True, mi_masks=masks, cache=cache)
+            else:
                 main = torch.cuda.current_stream()
+                side.wait_event(pipe.start)
+                xi_s, xi_t = self.model.encoder_imaging.run_pair(self.ema.encoder_imaging, x_img, cache, side)
+                with torch.no_grad(), torch.cuda.stream(side):  # the rest of the teacher has no hand-over: issue it first
+                    t = self.ema.forward_all((x_img, x_tab), train=False, cache=cache, x_i=xi_t)
+                    feat_m_e, _, _ = self.project_3features(torch.cat((t[3], t[9], t[6]), dim=1))
+                s = self.model.forward_all((x_img, x_tab), train=True, mi_masks=masks, cache=cache, x_i=xi_s)
                 main.wait_stream(side)
                 for tt in (*t, feat_m_e):
                     tt.record_stream(main)
