@@ -144,15 +144,20 @@ def main():
         byvar = {}
         for name, ms, meta in prof:
             if name == "gemm_nt" and meta:
-                c = byvar.setdefault(meta[0], [0, 0.0, 0.0])
-                c[0] += 1; c[1] += ms * 1e-3; c[2] += meta[1]
-        var, (nl, tsum, fsum) = max(byvar.items(), key=lambda kv: kv[1][1])
+                c = byvar.setdefault(meta[0], [0, 0.0, 0.0, 0.0])
+                c[0] += 1; c[1] += ms * 1e-3; c[2] += meta[1]; c[3] += meta[3]
+        var, (nl, tsum, fsum, bsum) = max(byvar.items(), key=lambda kv: kv[1][1])
         kname = {22: "gemm_nt_kernel<2, 2, 16, true>", 21: "gemm_nt_kernel<2, 1, 16, true>", 11: "gemm_nt_kernel<1, 1, 16, true>"}[var]
         achieved = fsum / tsum / 1e12 if tsum > 0 else 0.0
         roof = dict(bound="mfma", kernel=kname, achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS,
                     unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
                     launches_per_step=nl, avg_launch_us=round(tsum / max(1, nl) * 1e6, 2),
-                    flops_per_step=fsum, share_of_step_time=round(tsum / (dt / a.steps), 4))
+                    flops_per_step=fsum, share_of_step_time=round(tsum / (dt / a.steps), 4),
+                    algorithmic_bytes=round(bsum / max(1, nl)),
+                    note="kernel timed with HIP events on the last timed step, which runs single-stream; the other steps "
+                         "co-run a second HIP stream (EMA teacher, weight gradients), which inflates per-kernel durations in "
+                         "a rocprofv3 trace of the default command -- profiles/*_single_stream.csv is the same command with "
+                         "STIL_WGRAD_STREAM=0")
         # HBM traffic of that kernel: PMC counters cannot be read from inside the process; the latest separate-pass
         # rocprofv3 measurement of this same command is kept under profiles/ and quoted when it is for this kernel.
         try:

@@ -120,7 +120,9 @@ def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None,
     meta = None
     if L._prof is not None:  # bench bookkeeping: tile variant + ALGORITHMIC flops (strided dgrad gathers count the conv's flops)
         s2 = geom[7] * geom[7] if geom[9] == 1 else 1
-        meta = (L.gemm_nt_variant(M, N), 2.0 * M * N * K / s2, (M, N, K, geom[5], geom[7], geom[9]))
+        src = (M // (geom[3] * geom[4])) * geom[0] * geom[1] * geom[2]  # gather source (each element fetched once, ideally)
+        nbytes = 4.0 * (src + N * K + M * N * (1 + (resid is not None) + (pre is not None)))
+        meta = (L.gemm_nt_variant(M, N), 2.0 * M * N * K / s2, (M, N, K, geom[5], geom[7], geom[9]), nbytes)
     L.gemm_nt(_p(A), _p(W), _p(out), M, N, K, lda, ldb, ldc, *geom[:8], pads[0], pads[1], geom[9], *outmap,
               _p(bias), _p(sub), _p(scale), _p(shift), _p(resid),
               (ldc if resid is not None else 0), _p(pre), act, float(alpha), _stream(), meta=meta)
