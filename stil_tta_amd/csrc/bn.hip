@@ -268,25 +268,46 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned 
 }
 
 // ---- stem im2col: NCHW image -> col[M, Kp], k = c*KH*KW + ky*KW + kx (the reference weight order), zero padded
-__global__ void im2col_nchw_kernel(const float* __restrict__ x, float* __restrict__ col, int N, int Cin, int H, int W,
-                                   int OH, int OW, int KH, int KW, int stride, int pad, int Kp) {
-  long total = (long)N * OH * OW * Kp;
-  const int K = Cin * KH * KW;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int k = (int)(i % Kp);
-    long m = i / Kp;
-    float v = 0.f;
+// col[m][k] (k = (c, ky, kx), zero-padded to Kp, Kp % 4 == 0) from an NCHW image.  One thread owns one 16-byte quad
+// of a row and walks down the rows: the k -> (c, ky, kx) decode comes from a small LDS table, the m -> (n, oy, ox)
+// decode is two divisions per quad, stores are full float4 lines (HBM-write bound: 2 GB at B=256 / 224 px).
+__global__ __launch_bounds__(256) void im2col_nchw_kernel(const float* __restrict__ x, float* __restrict__ col, int N, int Cin,
+                                                           int H, int W, int OH, int OW, int KH, int KW, int stride, int pad,
+                                                           int Kp, int rows_per_block) {
+  extern __shared__ int ktab[];  // Kp entries: (c * KH + ky) << 8 | kx, or -1 for the padding columns
+  const int K = Cin * KH * KW, Q = Kp >> 2;
+  for (int k = threadIdx.x; k < Kp; k += blockDim.x) {
+    int v = -1;
     if (k < K) {
-      int ox = (int)(m % OW);
-      long t = m / OW;
-      int oy = (int)(t % OH);
-      int n = (int)(t / OH);
-      int c = k / (KH * KW), r = k - c * KH * KW;
-      int ky = r / KW, kx = r - ky * KW;
-      int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((long)(n * Cin + c) * H + iy) * W + ix];
+      const int c = k / (KH * KW), r = k - c * KH * KW, ky = r / KW, kx = r - ky * KW;
+      v = ((c * KH + ky) << 8) | kx;
     }
-    col[i] = v;
+    ktab[k] = v;
+  }
+  __syncthreads();
+  const long M = (long)N * OH * OW;
+  const long m0 = (long)blockIdx.x * rows_per_block;
+  const int quads = rows_per_block * Q;
+  for (int i = threadIdx.x; i < quads; i += blockDim.x) {
+    const int rr = i / Q, q = i - rr * Q;
+    const long m = m0 + rr;
+    if (m >= M) break;
+    const int ox = (int)(m % OW);
+    const long t = m / OW;
+    const int oy = (int)(t % OH), n = (int)(t / OH);
+    const int iy0 = oy * stride - pad, ix0 = ox * stride - pad;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = ktab[q * 4 + j];
+      v[j] = 0.f;
+      if (e >= 0) {
+        const int cky = e >> 8, kx = e & 255, c = cky / KH, ky = cky - c * KH;
+        const int iy = iy0 + ky, ix = ix0 + kx;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v[j] = x[((long)(n * Cin + c) * H + iy) * W + ix];
+      }
+    }
+    *reinterpret_cast<float4*>(col + m * Kp + q * 4) = make_float4(v[0], v[1], v[2], v[3]);
   }
 }
 
@@ -393,10 +414,11 @@ extern "C" int stil_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, 
 extern "C" int stil_im2col_nchw(const float* x, float* col, int N, int Cin, int H, int W, int OH, int OW, int KH,
                                 int KW, int stride, int pad, int Kp, void* stream) {
   STIL_REQUIRE(x && col && Kp >= Cin * KH * KW, "stil_im2col_nchw: null pointer or Kp too small");
-  long total = (long)N * OH * OW * Kp;
-  int grid = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
-  hipLaunchKernelGGL(im2col_nchw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, col, N, Cin, H, W, OH, OW,
-                     KH, KW, stride, pad, Kp);
+  STIL_REQUIRE(Kp % 4 == 0 && Kp <= 4096 && KW < 256 && ((uintptr_t)col % 16) == 0, "stil_im2col_nchw: Kp=%d must be a multiple of 4 (<= 4096), KW < 256, col 16-byte aligned", Kp);
+  const long M = (long)N * OH * OW;
+  const int rpb = 32;
+  hipLaunchKernelGGL(im2col_nchw_kernel, dim3(cdiv(M, rpb)), dim3(256), Kp * sizeof(int), (hipStream_t)stream, x, col, N, Cin, H, W,
+                     OH, OW, KH, KW, stride, pad, Kp, rpb);
   STIL_LAUNCH_CHECK();
   return STIL_OK;
 }
