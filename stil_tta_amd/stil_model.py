@@ -286,7 +286,10 @@ class STiLModel(_Base):
         x_img = torch.cat((im_l, im_u)).to(dev, torch.float32).contiguous()
         x_tab = torch.cat((tab_l, tab_u)).to(dev, torch.float32).contiguous()
         y_l = y_l.to(dev)
-        self._img_tokens = (x_img.shape[-1] // 32) * (x_img.shape[-2] // 32)
+        th, tw = x_img.shape[-2], x_img.shape[-1]
+        for _ in range(5):  # five stride-2 stages of the ResNet trunk (conv1, maxpool, layer2-4), each ceil(s / 2)
+            th, tw = (th + 1) // 2, (tw + 1) // 2
+        self._img_tokens = th * tw
         K, T, th = hp.num_classes, float(hp.temperature), float(hp.th1)
         use_pseudo = current_epoch > hp.start_epoch
         cache = {}

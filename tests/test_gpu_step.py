@@ -318,3 +318,51 @@ def test_side_stream_pipeline_is_bit_exact():
     assert a[0] == b[0]
     for x, y in zip(a[1:], b[1:]):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("label,over,B", [
+    ("all_continuous", dict(field_lengths=[1] * 5), 8),
+    ("all_categorical", dict(field_lengths=[3, 4, 5]), 8),
+    ("single_column", dict(field_lengths=[1]), 8),
+    ("img96_batch6", dict(field_lengths=[3, 1, 1], img_size=96), 6),          # B_l = 1, B_u = 5: ragged tiles everywhere
+    ("img100_not_multiple_of_32", dict(field_lengths=[3, 1, 1], img_size=100), 8),
+    ("three_classes_more_samples_than_tile", dict(field_lengths=[4, 1], num_classes=3), 72),  # M crosses a 64-row tile
+])
+def test_edge_layouts_match_oracle(label, over, B):
+    """Column layouts / image sizes / batch sizes the reference's modules accept (empty categorical or continuous part,
+    one column, maps that are not multiples of the tile sizes): one full step against the CPU oracle."""
+    from stil_tta_amd.driver import train_step
+    from stil_tta_amd.flat import StilAdam
+    from oracle.make_golden import randomize_state, make_mi_masks
+    base = dict(model="resnet18", embedding_dim=512, img_size=64, num_classes=5, batch_size=B, start_epoch=0, th1=0.05)
+    base.update(over)
+    hp = O.default_hparams(**base)
+    sd = randomize_state(O.init_state(hp, seed=11), seed=12)
+    g = torch.Generator().manual_seed(13)
+    sd["prototypes"] = torch.nn.functional.normalize(torch.randn(hp.num_classes, hp.projection_dim, generator=g))
+    m = _make_model(hp, {k: v.clone() for k, v in sd.items()})
+    m.current_epoch = 1
+    batch = O.synthetic_batch(hp, B, seed=21)
+    B_u = len(batch["u"][2])
+    mr = torch.rand(B_u, generator=g).ge(0.5)
+    s = hp.img_size
+    for _ in range(5):
+        s = (s + 1) // 2
+    mm = {0: make_mi_masks(B, s * s, len(hp.field_lengths), 512, 4, 0.1, seed=5)}
+    o = O.full_step(sd, {}, 1, batch, hp, 1, mr, mm)
+    train_step(m, StilAdam(m.flat, lr=hp.lr_eval), _to_dev(batch), mask_random=mr, mi_masks=mm)
+    torch.cuda.synchronize()
+    bad = []
+    for k in SCALARS + ["y_hat_m", "y_hat_i", "y_hat_t", "y_hat_m_e", "feat_m", "feat_i", "feat_t", "pseudo_label", "prediction", "class_sum", "class_count"]:
+        ok, err = _close(m.last[k].detach().cpu().numpy(), o[k].numpy())
+        if not ok:
+            bad.append((k, err))
+    _check_flags(m.last, o, B_u)
+    msd = m.state_dict()
+    tr = set(O.trainable_keys(sd))
+    for k, v in sd.items():
+        if k not in tr:
+            ok, err = _close(msd[k].cpu().double().numpy(), v.double().numpy(), 5e-5)
+            if not ok:
+                bad.append(("state " + k, err))
+    assert not bad, f"{label}: {len(bad)} mismatches, first: {bad[:8]}"
