@@ -76,7 +76,9 @@ int stil_transpose(const float* in, float* out, int R, int C, void* stream);
 
 /* ---- BatchNorm2d (NHWC rows), ReLU, residual, max-pool: models/resnets.py:112-132,248-252 ----
  * stats: [4,C] = mean, rstd, a=gamma*rstd, beta (z = (x-mean)*a + beta); bn_eval_affine's ab: [3,C] = a, beta, running_mean.  Train forward also updates the running
- * statistics (momentum, unbiased variance) and num_batches_tracked. z = relu?(x*a + b + resid). */
+ * statistics (momentum, unbiased variance) and num_batches_tracked. z = relu?(x*a + b + resid).
+ * bn_train_bwd's relu: 0 = none, 1 = mask (z > 0) read from z, 2 = mask recomputed from x and stats (only without
+ * a residual input; z may then be NULL).  gout (optional) receives dz*mask, the gradient of the residual branch. */
 size_t stil_bn_workspace_bytes(int M, int C);
 int stil_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
                       float* running_var, long long* num_batches_tracked, const float* resid, float* z,

@@ -137,17 +137,22 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
   const float4 mu = *reinterpret_cast<const float4*>(stats + c);
   const float4 rs = *reinterpret_cast<const float4*>(stats + C + c);
+  const float4 ap = *reinterpret_cast<const float4*>(stats + 2 * C + c);
+  const float4 bp = *reinterpret_cast<const float4*>(stats + 3 * C + c);
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
   for (int m = m0 + rl; m < m1; m += rpb) {
     const long o = (long)m * C + c;
     float4 g = *reinterpret_cast<const float4*>(dz + o);
-    if (relu) {
+    const float4 v = *reinterpret_cast<const float4*>(x + o);
+    if (relu == 1) {
       const float4 zz = *reinterpret_cast<const float4*>(z + o);
       g.x = zz.x > 0.f ? g.x : 0.f; g.y = zz.y > 0.f ? g.y : 0.f;
       g.z = zz.z > 0.f ? g.z : 0.f; g.w = zz.w > 0.f ? g.w : 0.f;
+    } else if (relu == 2) {  // no residual: z = relu((x - mean)*a + beta), the sign is recomputed exactly as bn_apply did
+      g.x = ((v.x - mu.x) * ap.x + bp.x) > 0.f ? g.x : 0.f; g.y = ((v.y - mu.y) * ap.y + bp.y) > 0.f ? g.y : 0.f;
+      g.z = ((v.z - mu.z) * ap.z + bp.z) > 0.f ? g.z : 0.f; g.w = ((v.w - mu.w) * ap.w + bp.w) > 0.f ? g.w : 0.f;
     }
     if (gout) *reinterpret_cast<float4*>(gout + o) = g;
-    const float4 v = *reinterpret_cast<const float4*>(x + o);
     s1.x += g.x; s2.x += g.x * ((v.x - mu.x) * rs.x);
     s1.y += g.y; s2.y += g.y * ((v.y - mu.y) * rs.y);
     s1.z += g.z; s2.z += g.z * ((v.z - mu.z) * rs.z);
@@ -194,13 +199,18 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)((i * 4) % C);
     float4 g = reinterpret_cast<const float4*>(dz)[i];
-    if (relu) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 mu = *reinterpret_cast<const float4*>(stats + c);
+    if (relu == 1) {
       const float4 zz = reinterpret_cast<const float4*>(z)[i];
       g.x = zz.x > 0.f ? g.x : 0.f; g.y = zz.y > 0.f ? g.y : 0.f;
       g.z = zz.z > 0.f ? g.z : 0.f; g.w = zz.w > 0.f ? g.w : 0.f;
+    } else if (relu == 2) {
+      const float4 ap = *reinterpret_cast<const float4*>(stats + 2 * C + c);
+      const float4 bp = *reinterpret_cast<const float4*>(stats + 3 * C + c);
+      g.x = ((v.x - mu.x) * ap.x + bp.x) > 0.f ? g.x : 0.f; g.y = ((v.y - mu.y) * ap.y + bp.y) > 0.f ? g.y : 0.f;
+      g.z = ((v.z - mu.z) * ap.z + bp.z) > 0.f ? g.z : 0.f; g.w = ((v.w - mu.w) * ap.w + bp.w) > 0.f ? g.w : 0.f;
     }
-    const float4 v = reinterpret_cast<const float4*>(x)[i];
-    const float4 mu = *reinterpret_cast<const float4*>(stats + c);
     const float4 rs = *reinterpret_cast<const float4*>(stats + C + c);
     const float4 k1 = *reinterpret_cast<const float4*>(coef + c);
     const float4 k2 = *reinterpret_cast<const float4*>(coef + C + c);
@@ -361,14 +371,15 @@ extern "C" int stil_bn_eval_affine(const float* gamma, const float* beta, const 
   return STIL_OK;
 }
 
-// dz: grad wrt the block output; z: that output (relu mask); x: conv output (pre-BN).
-// gout (optional): receives g = dz*(z>0) (the gradient of the residual branch).  coef: [3*C] scratch.
+// dz: grad wrt the block output; z: that output; x: conv output (pre-BN).  relu: 0 = none, 1 = mask from z (z > 0),
+// 2 = mask recomputed from x and the saved statistics (only valid without a residual input: saves reading z twice).
+// gout (optional): receives g = dz*mask (the gradient of the residual branch).  coef: [3*C] scratch.
 extern "C" int stil_bn_train_bwd(const float* dz, const float* z, const float* x, const float* gamma,
                                  const float* stats, float* dx, float* gout, float* dgamma, float* dbeta, float* coef,
                                  int M, int C, int relu, int accumulate, float* workspace, size_t workspace_bytes,
                                  void* stream) {
   STIL_REQUIRE(dz && x && gamma && stats && dx && coef && workspace, "stil_bn_train_bwd: null pointer");
-  STIL_REQUIRE(!relu || z, "stil_bn_train_bwd: relu needs z");
+  STIL_REQUIRE(relu >= 0 && relu <= 2 && (relu != 1 || z), "stil_bn_train_bwd: relu must be 0, 1 (needs z) or 2");
   int ct = pick_ctile(C);
   STIL_REQUIRE(ct != 0, "stil_bn_train_bwd: C=%d must be a multiple of 64", C);
   int nch = bn_chunks(M, C, ct);

@@ -325,7 +325,7 @@ class ConvBnActFn(torch.autograd.Function):
         dbeta = bslot if bslot is not None else torch.empty_like(beta)
         acc = 1 if gslot is not None else 0
         lib().bn_train_bwd(_p(gz), _p(z), _p(y), _p(gamma), _p(stats), _p(dy), _p(gres), _p(dgamma), _p(dbeta), _p(coef), M,
-                           Cout, 1 if relu else 0, acc, _p(ws), nb, _stream())
+                           Cout, (1 if has_res else 2) if relu else 0, acc, _p(ws), nb, _stream())
         if gslot is not None:
             gamma._stil_touched = True
             beta._stil_touched = True
