@@ -37,13 +37,17 @@ int stil_device_count(void);
  * (out_stride 1 = identity): the input-gradient of a stride-s conv is s*s such launches, one per output phase, each a
  * stride-1 gather over its own tap subset (stil_conv_weight_layout_phase) -- no multiply-by-zero work.
  * `pre` (optional) receives the value before the activation.  act: 0 none, 1 ReLU, 2 GELU(erf).
+ * `colstats` (optional, raw product only): [2*cdiv(M,T), N] per-tile column statistics of C over tiles of
+ * T = stil_gemm_nt_tile_rows(M,N) rows -- row 2t = mean, row 2t+1 = sum of squared deviations over tile t's valid rows --
+ * which stil_bn_train_fwd_tiles turns into the batch statistics without a second pass over C.
  * Replaces nn.Conv2d / nn.Linear forward and input-gradient: models/resnets.py:112-132,248-260,
  * models/Transformer.py:27-33,63-88, STiLModel_backbone.py:19-32,139,153-155. */
 int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                  int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad_y, int pad_x,
                  int mode, int out_stride, int out_py, int out_px, int out_OH, int out_OW,
                  const float* bias, const float* sub, const float* scale, const float* shift, const float* resid,
-                 int ldr, float* pre, int act, float alpha, void* stream);
+                 int ldr, float* pre, int act, float alpha, float* colstats, void* stream);
+int stil_gemm_nt_tile_rows(int M, int N);
 
 /* tile variant stil_gemm_nt launches for an [M,N] output: 22 = 128x128, 21 = 128x64, 11 = 64x64 (bench bookkeeping) */
 int stil_gemm_nt_variant(int M, int N);
@@ -84,6 +88,11 @@ int stil_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
                       float* running_var, long long* num_batches_tracked, const float* resid, float* z,
                       float* stats, int M, int C, int relu, float eps, float momentum, float* workspace,
                       size_t workspace_bytes, void* stream);
+int stil_bn_train_fwd_tiles(const float* x, const float* tilestats, int tile_rows, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, long long* num_batches_tracked,
+                            const float* resid, float* z, float* stats, int M, int C, int relu, float eps,
+                            float momentum, void* workspace, size_t workspace_bytes, void* stream);
+size_t stil_bn_tiles_workspace_bytes(int M, int C, int tile_rows);
 int stil_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float* ab, int C, float eps, void* stream);
 int stil_bn_train_bwd(const float* dz, const float* z, const float* x, const float* gamma,

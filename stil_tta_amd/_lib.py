@@ -88,7 +88,7 @@ class _Lib:
     def __getattr__(self, name):
         fn = getattr(self._dll, "stil_" + name)
         restype = self.protos["stil_" + name][0]
-        if restype is not ctypes.c_int or name in ("version", "device_count", "gemm_nt_variant"):
+        if restype is not ctypes.c_int or name in ("version", "device_count", "gemm_nt_variant", "gemm_nt_tile_rows"):
             return fn
 
         def call(*args, meta=None):

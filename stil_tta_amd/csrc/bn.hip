@@ -92,6 +92,58 @@ __global__ __launch_bounds__(1024) void bn_stats_final_kernel(const float* __res
   }
 }
 
+// Same outputs from the per-tile (mean_t, M2_t) partials the conv GEMM's epilogue wrote (stil_gemm_nt colstats).
+// With n_t rows in tile t:  mean = S1/M,  M2 = S3 + (S2 - S1^2/M),  S1 = sum n_t mean_t, S2 = sum n_t mean_t^2, S3 = sum M2_t.
+// The three sums run in DOUBLE (every term is an exact product of floats, so the S2 - S1^2/M cancellation costs nothing),
+// split over `nsplit` blocks per 32 columns (stage 1) and added in a fixed order (stage 2): deterministic.
+__global__ __launch_bounds__(1024) void bn_tiles_stage1_kernel(const float* __restrict__ ts, int nt, int tile_rows, int M, int C,
+                                                                int tiles_per_split, double* __restrict__ part) {
+  __shared__ double sh[3 * 32 * 32];
+  const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const int t0 = blockIdx.y * tiles_per_split, t1 = min(nt, t0 + tiles_per_split);
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (c < C)
+    for (int t = t0 + lane; t < t1; t += 32) {
+      const double n = (double)min(tile_rows, M - t * tile_rows);
+      const double m = (double)ts[((long)t * 2) * C + c];
+      s1 += n * m; s2 += n * m * m; s3 += (double)ts[((long)t * 2 + 1) * C + c];
+    }
+  sh[lane * 32 + cl] = s1; sh[1024 + lane * 32 + cl] = s2; sh[2048 + lane * 32 + cl] = s3;
+  __syncthreads();
+  if (lane != 0 || c >= C) return;
+  double a = 0.0, b = 0.0, d = 0.0;
+  for (int l = 0; l < 32; ++l) { a += sh[l * 32 + cl]; b += sh[1024 + l * 32 + cl]; d += sh[2048 + l * 32 + cl]; }
+  const int nsplit = gridDim.y;
+  part[((long)0 * nsplit + blockIdx.y) * C + c] = a;
+  part[((long)1 * nsplit + blockIdx.y) * C + c] = b;
+  part[((long)2 * nsplit + blockIdx.y) * C + c] = d;
+}
+
+__global__ __launch_bounds__(256) void bn_tiles_stage2_kernel(const double* __restrict__ part, int nsplit, int M, int C,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      float* __restrict__ rmean, float* __restrict__ rvar, long long* nbt,
+                                      float* __restrict__ stats, float eps, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  for (int k = 0; k < nsplit; ++k) {
+    s1 += part[((long)0 * nsplit + k) * C + c]; s2 += part[((long)1 * nsplit + k) * C + c]; s3 += part[((long)2 * nsplit + k) * C + c];
+  }
+  const double mean_d = s1 / (double)M;
+  double m2 = s3 + (s2 - s1 * mean_d);
+  const float mean = (float)mean_d;
+  const float var = fmaxf((float)(m2 / (double)M), 0.f);
+  const float rstd = 1.f / sqrtf(var + eps);
+  stats[c] = mean; stats[C + c] = rstd; stats[2 * C + c] = gamma[c] * rstd; stats[3 * C + c] = beta[c];
+  if (rmean) {
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+    const float unb = (M > 1) ? var * ((float)M / (float)(M - 1)) : var;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+  }
+}
+
 // eval mode: ab[0] = a = gamma / sqrt(running_var + eps), ab[1] = beta, ab[2] = running_mean.  The conv epilogue
 // applies (y - mean) * a + beta: the subtractive form keeps ATen's accuracy (no x*a - mean*a cancellation).
 __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -367,6 +419,35 @@ extern "C" int stil_bn_eval_affine(const float* gamma, const float* beta, const 
   STIL_REQUIRE(gamma && beta && running_mean && running_var && ab, "stil_bn_eval_affine: null pointer");
   hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, gamma, beta,
                      running_mean, running_var, ab, C, eps);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+// Training forward when the producing GEMM already wrote per-tile statistics (tilestats: [2*cdiv(M,tile_rows), C]).
+static inline int bn_tiles_nsplit(int nt) { return cdiv(nt, 512); }
+extern "C" size_t stil_bn_tiles_workspace_bytes(int M, int C, int tile_rows) {
+  if (M <= 0 || C <= 0 || tile_rows <= 0) return 0;
+  return (size_t)3 * bn_tiles_nsplit(cdiv(M, tile_rows)) * C * sizeof(double);
+}
+extern "C" int stil_bn_train_fwd_tiles(const float* x, const float* tilestats, int tile_rows, const float* gamma, const float* beta,
+                                       float* running_mean, float* running_var, long long* num_batches_tracked,
+                                       const float* resid, float* z, float* stats, int M, int C, int relu, float eps,
+                                       float momentum, void* workspace, size_t workspace_bytes, void* stream) {
+  STIL_REQUIRE(x && tilestats && gamma && beta && z && stats && workspace, "stil_bn_train_fwd_tiles: null pointer");
+  STIL_REQUIRE(tile_rows > 0 && M > 0 && C % 4 == 0, "stil_bn_train_fwd_tiles: bad shape M=%d C=%d tile_rows=%d", M, C, tile_rows);
+  STIL_REQUIRE(workspace_bytes >= stil_bn_tiles_workspace_bytes(M, C, tile_rows) && ((uintptr_t)workspace % 8) == 0,
+               "stil_bn_train_fwd_tiles: workspace too small or not 8-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int nt = cdiv(M, tile_rows), nsplit = bn_tiles_nsplit(nt);
+  hipLaunchKernelGGL(bn_tiles_stage1_kernel, dim3(cdiv(C, 32), nsplit), dim3(1024), 0, s, tilestats, nt, tile_rows, M, C,
+                     cdiv(nt, nsplit), (double*)workspace);
+  STIL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_tiles_stage2_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)workspace, nsplit, M, C, gamma, beta,
+                     running_mean, running_var, num_batches_tracked, stats, eps, momentum);
+  STIL_LAUNCH_CHECK();
+  long total4 = (long)M * C / 4;
+  int grid = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, s, x, stats, resid, z, total4, C, relu);
   STIL_LAUNCH_CHECK();
   return STIL_OK;
 }

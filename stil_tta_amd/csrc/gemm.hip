@@ -45,6 +45,9 @@ struct GemmNTArgs {
   // output row map: GEMM row m = (n, oy', ox') over the OHxOW grid is written to row
   // (n*oOH + oy'*os + opy)*oOW + ox'*os + opx of C (os == 1: identity).  Used by the phase-decomposed strided dgrad.
   int os, opy, opx, oOH, oOW;
+  // optional per-tile column statistics of the stored output (training BatchNorm without a statistics pass over C):
+  // colstats[(tm*2 + 0)*N + col] = mean over the tile's valid rows, [(tm*2 + 1)*N + col] = sum of squared deviations
+  float* colstats;
 };
 
 __device__ __forceinline__ float4 ld4_guard(const float* p, int nvalid, int vec) {
@@ -224,6 +227,58 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
     }
   };
   if (full) mainloop(std::true_type{}); else mainloop(std::false_type{});
+
+  // per-tile column mean / M2 (Welford partials, combined in fixed order by bn_stats_final_tiles_kernel)
+  if (p.colstats) {
+    float* red = lds;   // [2 (wm)][BN]; the main loop's last barrier has retired every LDS read
+    const int rows_valid = min(BM, p.M - tm * BM);
+    float mean_t[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row_m = tm * BM + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (row_m < p.M) sacc += acc[i][j][r] * p.alpha;
+        }
+      sacc += __shfl_xor(sacc, 32, 64);
+      if (lh == 0) red[wm * BN + wn * TN * 32 + j * 32 + li] = sacc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int cs = wn * TN * 32 + j * 32 + li;
+      mean_t[j] = (red[cs] + red[BN + cs]) / (float)rows_valid;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row_m = tm * BM + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const float d = acc[i][j][r] * p.alpha - mean_t[j];
+          if (row_m < p.M) q += d * d;
+        }
+      q += __shfl_xor(q, 32, 64);
+      if (lh == 0) red[wm * BN + wn * TN * 32 + j * 32 + li] = q;
+    }
+    __syncthreads();
+    if (wm == 0 && lh == 0) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int cs = wn * TN * 32 + j * 32 + li, col = tn * BN + cs;
+        if (col < p.N) {
+          p.colstats[((long)tm * 2) * p.N + col] = mean_t[j];
+          p.colstats[((long)tm * 2 + 1) * p.N + col] = red[cs] + red[BN + cs];
+        }
+      }
+    }
+  }
 
   // epilogue: C/D map of 32x32 tiles: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -489,12 +544,15 @@ extern "C" int stil_gemm_nt_variant(int M, int N) {
   return 11;
 }
 
+// rows per output tile of the variant stil_gemm_nt picks for [M,N] (the granularity of `colstats`)
+extern "C" int stil_gemm_nt_tile_rows(int M, int N) { return stil_gemm_nt_variant(M, N) == 11 ? 64 : 128; }
+
 extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                             int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad_y,
                             int pad_x, int mode, int out_stride, int out_py, int out_px, int out_OH, int out_OW,
                             const float* bias, const float* sub, const float* scale,
                             const float* shift, const float* resid, int ldr, float* pre, int act, float alpha,
-                            void* stream) {
+                            float* colstats, void* stream) {
   STIL_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0, "stil_gemm_nt: null pointer or empty shape (M=%d N=%d K=%d)", M, N, K);
   STIL_REQUIRE(KH * KW * srcC == K, "stil_gemm_nt: K=%d != KH*KW*C=%d", K, KH * KW * srcC);
   STIL_REQUIRE(M % (OH * OW) == 0, "stil_gemm_nt: M=%d not a multiple of OH*OW=%d", M, OH * OW);
@@ -504,6 +562,9 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   p.os = out_stride < 1 ? 1 : out_stride; p.opy = out_py; p.opx = out_px; p.oOH = out_OH; p.oOW = out_OW;
   p.bias = bias; p.sub = sub; p.scale = scale; p.shift = shift; p.resid = resid; p.ldr = ldr; p.pre = pre; p.act = act;
   p.alpha = alpha;
+  p.colstats = colstats;
+  STIL_REQUIRE(!colstats || (p.os == 1 && !bias && !sub && !scale && !shift && !resid && act == 0),
+               "stil_gemm_nt: colstats describes the raw product (no bias / affine / residual / activation / output map)");
   p.vecA = is_vec(A, lda) && (srcC % 4 == 0);
   p.vecB = is_vec(W, ldb);
   int rc = check_geom(p.g, 0);

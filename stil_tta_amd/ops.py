@@ -103,7 +103,7 @@ def _grad_into(param: torch.Tensor, writer):
 
 # ------------------------------------------------------------------------------------------ raw wrappers
 def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None, bias=None, sub=None, scale=None, shift=None,
-            resid=None, pre=None, act=0, alpha=1.0, pads=None, outmap=None, out_rows=None):
+            resid=None, pre=None, act=0, alpha=1.0, pads=None, outmap=None, out_rows=None, colstats=None):
     """C = epilogue(alpha * Agather . W^T).  geom = (srcH, srcW, srcC, OH, OW, KH, KW, stride, pad, mode);
     pads = (pad_y, pad_x) overrides geom's pad; outmap = (out_stride, py, px, out_OH, out_OW) scatters GEMM row
     (n, oy, ox) to output row (n*out_OH + oy*s + py)*out_OW + ox*s + px (out_rows = rows of `out` then)."""
@@ -125,7 +125,7 @@ def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None,
         meta = (L.gemm_nt_variant(M, N), 2.0 * M * N * K / s2, (M, N, K, geom[5], geom[7], geom[9]), nbytes)
     L.gemm_nt(_p(A), _p(W), _p(out), M, N, K, lda, ldb, ldc, *geom[:8], pads[0], pads[1], geom[9], *outmap,
               _p(bias), _p(sub), _p(scale), _p(shift), _p(resid),
-              (ldc if resid is not None else 0), _p(pre), act, float(alpha), _stream(), meta=meta)
+              (ldc if resid is not None else 0), _p(pre), act, float(alpha), _p(colstats), _stream(), meta=meta)
     return out
 
 
@@ -261,6 +261,9 @@ def _conv_geom_fwd(H, W, C, OH, OW, k, stride, pad):
     return (H, W, C, OH, OW, k, k, stride, pad, 0)
 
 
+_BN_EPILOGUE_STATS = __import__("os").environ.get("STIL_BN_EPILOGUE_STATS", "1") != "0"
+
+
 class ConvBnActFn(torch.autograd.Function):
     """z = relu?( BN_train(conv(x, w)) + residual? ) on NHWC activations.
 
@@ -277,30 +280,43 @@ class ConvBnActFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         Cout = w.shape[0]
         dev = x.device
+        fused = _BN_EPILOGUE_STATS and Cout % 4 == 0
         if stem is not None:  # x is col [M, Kp]; stem = (N, OH, OW, Kp, wpad)
             Nb, OH, OW, Kp, wpad = stem
             M = Nb * OH * OW
-            y = gemm_nt(x, wpad, M, Cout, Kp)
-            wf = None
-            geom = None
         else:
             Nb, H, W_, Cin = x.shape
             OH = (H + 2 * pad - k) // stride + 1
             OW = (W_ + 2 * pad - k) // stride + 1
             M = Nb * OH * OW
+        ts = tile_rows = None
+        if fused:  # the GEMM epilogue leaves per-tile (mean, M2) partials: no statistics pass over y
+            tile_rows = lib().gemm_nt_tile_rows(M, Cout)
+            ts = torch.empty((2 * ((M + tile_rows - 1) // tile_rows), Cout), dtype=torch.float32, device=dev)
+        if stem is not None:
+            y = gemm_nt(x, wpad, M, Cout, Kp, colstats=ts)
+            wf = None
+            geom = None
+        else:
             if k == 1:
                 wf = w.reshape(Cout, Cin)
             else:
                 wf = torch.empty((Cout, k * k * Cin), dtype=torch.float32, device=dev)
                 lib().conv_weight_layout(_p(w), _p(wf), None, Cout, Cin, k, k, _stream())
             geom = _conv_geom_fwd(H, W_, Cin, OH, OW, k, stride, pad)
-            y = gemm_nt(x, wf, M, Cout, k * k * Cin, geom=geom)
+            y = gemm_nt(x, wf, M, Cout, k * k * Cin, geom=geom, colstats=ts)
         stats = torch.empty((4, Cout), dtype=torch.float32, device=dev)
         z = torch.empty((M, Cout), dtype=torch.float32, device=dev)
-        nb = lib().bn_workspace_bytes(M, Cout)
-        ws = _ws.get(nb, dev)
-        lib().bn_train_fwd(_p(y), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(nbt), _p(resid), _p(z), _p(stats), M, Cout,
-                           1 if relu else 0, 1e-5, 0.1, _p(ws), nb, _stream())
+        if fused:
+            nb = lib().bn_tiles_workspace_bytes(M, Cout, tile_rows)
+            ws = _ws.get(nb, dev)
+            lib().bn_train_fwd_tiles(_p(y), _p(ts), tile_rows, _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(nbt), _p(resid), _p(z),
+                                     _p(stats), M, Cout, 1 if relu else 0, 1e-5, 0.1, _p(ws), nb, _stream())
+        else:
+            nb = lib().bn_workspace_bytes(M, Cout)
+            ws = _ws.get(nb, dev)
+            lib().bn_train_fwd(_p(y), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(nbt), _p(resid), _p(z), _p(stats), M, Cout,
+                               1 if relu else 0, 1e-5, 0.1, _p(ws), nb, _stream())
         ctx.save_for_backward(x, w, gamma, beta, y, z, stats)
         ctx.cfg = (k, stride, pad, relu, stem is not None, resid is not None, geom, (Nb, OH, OW), stem)
         if passthrough:
