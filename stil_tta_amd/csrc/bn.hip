@@ -277,55 +277,71 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
 }
 
 // ---- max-pool 3x3 s2 p1 (NHWC).  idx = ky*3+kx of the FIRST maximum in scan order (ATen tie rule).
-__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx,
-                                   int N, int H, int W, int C, int OH, int OW) {
-  long total = (long)N * OH * OW * C;
+// four channels per thread (C % 4 == 0): 16-byte loads / stores, one (n, oy, ox) decode per 4 elements
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx,
+                                                           int N, int H, int W, int C, int OH, int OW) {
+  const int C4 = C >> 2;
+  const long total = (long)N * OH * OW * C4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int c = (int)(i % C);
-    long t = i / C;
-    int ox = (int)(t % OW); t /= OW;
-    int oy = (int)(t % OH);
-    int n = (int)(t / OH);
-    float best = -INFINITY;
-    int bi = 0;
+    const int c = (int)(i % C4) * 4;
+    long t = i / C4;
+    const int ox = (int)(t % OW); t /= OW;
+    const int oy = (int)(t % OH);
+    const int n = (int)(t / OH);
+    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    int b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+#pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
-      int iy = oy * 2 - 1 + ky;
+      const int iy = oy * 2 - 1 + ky;
       if (iy < 0 || iy >= H) continue;
+#pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        int ix = ox * 2 - 1 + kx;
+        const int ix = ox * 2 - 1 + kx;
         if (ix < 0 || ix >= W) continue;
-        float v = x[((long)(n * H + iy) * W + ix) * C + c];
-        if (v > best || v != v) { best = v; bi = ky * 3 + kx; }
+        const float4 v = *reinterpret_cast<const float4*>(x + ((long)(n * H + iy) * W + ix) * C + c);
+        const int tap = ky * 3 + kx;
+        if (v.x > best.x || v.x != v.x) { best.x = v.x; b0 = tap; }
+        if (v.y > best.y || v.y != v.y) { best.y = v.y; b1 = tap; }
+        if (v.z > best.z || v.z != v.z) { best.z = v.z; b2 = tap; }
+        if (v.w > best.w || v.w != v.w) { best.w = v.w; b3 = tap; }
       }
     }
-    y[i] = best;
-    idx[i] = (unsigned char)bi;
+    const long o = ((long)(n * OH + oy) * OW + ox) * C + c;
+    *reinterpret_cast<float4*>(y + o) = best;
+    *reinterpret_cast<uchar4*>(idx + o) = make_uchar4((unsigned char)b0, (unsigned char)b1, (unsigned char)b2, (unsigned char)b3);
   }
 }
 
-__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ idx,
-                                   float* __restrict__ dx, int N, int H, int W, int C, int OH, int OW) {
-  long total = (long)N * H * W * C;
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                                           float* __restrict__ dx, int N, int H, int W, int C, int OH, int OW) {
+  const int C4 = C >> 2;
+  const long total = (long)N * H * W * C4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int c = (int)(i % C);
-    long t = i / C;
-    int ix = (int)(t % W); t /= W;
-    int iy = (int)(t % H);
-    int n = (int)(t / H);
-    float s = 0.f;
+    const int c = (int)(i % C4) * 4;
+    long t = i / C4;
+    const int ix = (int)(t % W); t /= W;
+    const int iy = (int)(t % H);
+    const int n = (int)(t / H);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {
       if (oy < 0 || oy >= OH) continue;
-      int ky = iy - (oy * 2 - 1);
+      const int ky = iy - (oy * 2 - 1);
       if (ky < 0 || ky > 2) continue;
       for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
         if (ox < 0 || ox >= OW) continue;
-        int kx = ix - (ox * 2 - 1);
+        const int kx = ix - (ox * 2 - 1);
         if (kx < 0 || kx > 2) continue;
-        long o = ((long)(n * OH + oy) * OW + ox) * C + c;
-        if (idx[o] == ky * 3 + kx) s += dy[o];
+        const long o = ((long)(n * OH + oy) * OW + ox) * C + c;
+        const uchar4 k = *reinterpret_cast<const uchar4*>(idx + o);
+        const float4 g = *reinterpret_cast<const float4*>(dy + o);
+        const int tap = ky * 3 + kx;
+        if (k.x == tap) s.x += g.x;
+        if (k.y == tap) s.y += g.y;
+        if (k.z == tap) s.z += g.z;
+        if (k.w == tap) s.w += g.w;
       }
     }
-    dx[i] = s;
+    *reinterpret_cast<float4*>(dx + ((long)(n * H + iy) * W + ix) * C + c) = s;
   }
 }
 
@@ -486,7 +502,8 @@ extern "C" int stil_maxpool3x3s2_fwd(const float* x, float* y, unsigned char* id
                                      int OW, void* stream) {
   STIL_REQUIRE(x && y && idx, "stil_maxpool3x3s2_fwd: null pointer");
   STIL_REQUIRE(OH == (H + 2 - 3) / 2 + 1 && OW == (W + 2 - 3) / 2 + 1, "stil_maxpool3x3s2_fwd: bad output dims");
-  long total = (long)N * OH * OW * C;
+  STIL_REQUIRE(C % 4 == 0, "stil_maxpool3x3s2_fwd: C=%d must be a multiple of 4", C);
+  long total = (long)N * OH * OW * C / 4;
   int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, idx, N, H, W, C, OH, OW);
   STIL_LAUNCH_CHECK();
@@ -496,7 +513,8 @@ extern "C" int stil_maxpool3x3s2_fwd(const float* x, float* y, unsigned char* id
 extern "C" int stil_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, float* dx, int N, int H, int W, int C,
                                      int OH, int OW, void* stream) {
   STIL_REQUIRE(dy && idx && dx, "stil_maxpool3x3s2_bwd: null pointer");
-  long total = (long)N * H * W * C;
+  STIL_REQUIRE(C % 4 == 0, "stil_maxpool3x3s2_bwd: C=%d must be a multiple of 4", C);
+  long total = (long)N * H * W * C / 4;
   int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, N, H, W, C, OH, OW);
   STIL_LAUNCH_CHECK();
