@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (driver.GraphedTrainStep)")
+    ap.add_argument("--host-input", action="store_true", help="every step's batch starts in pageable host memory and goes through "
+                    "data.DevicePrefetcher (PCIe-inclusive rate; NOT the contract's `value`, which has inputs resident in HBM)")
     ap.add_argument("--breakdown", action="store_true", help="also print per-entry-point GPU time of the last step (stderr)")
     return ap.parse_args()
 
@@ -109,8 +111,13 @@ def main():
         gstep = GraphedTrainStep(m, opt, batch, warmup=max(1, a.warmup))
         eager_step = train_step
         train_step = lambda m_, o_, b_: gstep(b_)  # noqa: E731
+    feed = None
+    if a.host_input:
+        from stil_tta_amd.data import DevicePrefetcher
+        host_batch = synthetic_batch(fl, a.classes, a.batch, a.img, seed=2022 + rank, device="cpu")
+        feed = iter(DevicePrefetcher((host_batch for _ in range(a.warmup + a.steps)), dev, depth=2))
     for _ in range(a.warmup):
-        train_step(m, opt, batch)
+        train_step(m, opt, next(feed) if feed else batch)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -118,6 +125,8 @@ def main():
     L = lib()
     prof = None
     for s in range(a.steps):
+        if feed:
+            batch = next(feed)
         if s == a.steps - 1:
             L.begin_profile()  # HIP events around every C-ABI launch of the last timed step (same stream)
         if a.graph and s == a.steps - 1:
@@ -176,7 +185,8 @@ def main():
                                         f"({a.batch // 8} labelled + {a.batch - a.batch // 8} unlabelled), {a.img}x{a.img} + "
                                         f"{a.ncat + a.ncon} columns, K={a.classes}, epoch > start_epoch, MI dropout on",
                                global_batch=a.batch * world, parallelism=f"dp{world}", precision="fp32-exact MFMA",
-                               launch="hipGraph replay" if a.graph else "eager"),
+                               launch="hipGraph replay" if a.graph else "eager",
+                               input="host memory through data.DevicePrefetcher (PCIe-inclusive)" if a.host_input else "resident in HBM"),
                    roofline=roof, loss=round(loss, 5))
         if fps:
             out["step_tflops_algorithmic"] = round(value * fps / 1e12, 2)

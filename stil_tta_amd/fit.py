@@ -193,7 +193,7 @@ def validate(model, val_loader, limit_batches: Optional[int] = None) -> Dict[str
 def fit(model, train_loaders: Dict[str, Iterable], val_loader: Optional[Iterable] = None, *, max_epochs: Optional[int] = None,
         eval_metric: str = "acc", logdir: Optional[str] = None, check_val_every_n_epoch: int = 1, val_check_interval: float = 1.0,
         sweep: bool = False, limit_train_batches: Optional[int] = None, limit_val_batches: Optional[int] = None,
-        resume_from: Optional[str] = None, verbose: bool = True) -> dict:
+        resume_from: Optional[str] = None, verbose: bool = True, prefetch: bool = True) -> dict:
     """Trainer.fit(model, {'l','u'}, val_loader) of trainers/evaluate.py:178-179.  Returns the run summary
     (best score / epoch, checkpoint path, last callback metrics, why it stopped)."""
     model.setup_device()
@@ -217,7 +217,11 @@ def fit(model, train_loaders: Dict[str, Iterable], val_loader: Optional[Iterable
     for epoch in range(start_epoch, max_epochs):
         model.train()
         model.current_epoch = epoch
-        for i, batch in enumerate(max_size_cycle(train_loaders)):
+        stream = max_size_cycle(train_loaders)
+        if prefetch:  # host batches: pinned staging + H2D copies on a copy stream, two batches ahead (data.DevicePrefetcher)
+            from .data import DevicePrefetcher
+            stream = DevicePrefetcher(stream, dev, depth=2)
+        for i, batch in enumerate(stream):
             if limit_train_batches is not None and i >= limit_train_batches:
                 break
             train_step(model, opt, _to_device(batch, dev))

@@ -101,3 +101,27 @@ def test_early_stopping_ends_fit(tmp_path):
     loaders = {"l": _Pairs(li, lt, ly, 2, True), "u": _Pairs(ui, ut, uy, 14, False)}
     out = F.fit(m, loaders, _Val(vi, vt, vy, 16), max_epochs=50, val_check_interval=50.0, logdir=None, verbose=False)  # patience int(100/50) = 2
     assert out["stopped"] == "early_stopping" and out["epochs_run"] == 3
+
+
+def test_device_prefetcher_preserves_batches_and_order():
+    """Pinned-buffer double buffering on the copy stream hands out exactly the producer's batches, in order, with the
+    structure intact, also when staging slots are reused (more batches than slots) and shapes vary (last ragged batch)."""
+    from stil_tta_amd.data import DevicePrefetcher
+    g = torch.Generator().manual_seed(0)
+    batches = []
+    for i in range(7):
+        b = 5 if i == 6 else 8
+        batches.append({"l": ([torch.zeros(b), torch.rand(b, 3, 16, 16, generator=g)], [torch.rand(b, 4, generator=g)] * 2,
+                              torch.randint(0, 3, (b,), generator=g), torch.rand(b, 3, 16, 16, generator=g), torch.ones(b, dtype=torch.bool)),
+                        "idx": i})
+    seen = 0
+    for i, got in enumerate(DevicePrefetcher(batches, "cuda", depth=2)):
+        ref = batches[i]
+        assert got["idx"] == i
+        im, tab, y, orig, ident = got["l"]
+        assert im[1].is_cuda and tab[0].is_cuda and y.is_cuda and ident.dtype == torch.bool
+        torch.cuda.current_stream().synchronize()
+        assert torch.equal(im[1].cpu(), ref["l"][0][1]) and torch.equal(tab[1].cpu(), ref["l"][1][1])
+        assert torch.equal(y.cpu(), ref["l"][2]) and torch.equal(orig.cpu(), ref["l"][3])
+        seen += 1
+    assert seen == 7
