@@ -200,6 +200,11 @@ int stil_proto_add(const float* class_sum_cnt, float* prototypes_sum, float* pro
 int stil_proto_commit(float* prototypes, float* prototypes_sum, float* prototypes_count_sum,
                       int* bad_count_dev, int K, int Dp, void* stream);
 
+/* hard pseudo-labels of the MMatch baseline (models/SemiMultimodal/MMatch.py:223-226): onehot[r] = e_argmax(probs[r]) (first
+ * maximum), row_mask[r] = (max >= threshold) as 0/1 floats, idx[r] = the argmax */
+int stil_onehot_argmax(const float* probs, int rows, int K, float threshold, float* onehot, float* row_mask, int* idx,
+                       void* stream);
+
 /* ---- flat-slab EMA teacher update and Adam: STiLModel.py:154-168, 563-570 */
 int stil_ema_update(float* ema, const float* model, long n, double momentum, void* stream);
 int stil_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,

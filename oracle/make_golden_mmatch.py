@@ -1,0 +1,186 @@
+"""Pin oracle/mmatch_oracle.py against the REAL reference MMatch (models/SemiMultimodal/MMatch.py) and write
+tests/golden/mmatch_*.npz.  Build container only (needs /root/reference); same stub recipe as make_golden.py.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden_mmatch.py
+"""
+from __future__ import annotations
+
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from oracle import stil_oracle as O  # noqa: E402
+from oracle import mmatch_oracle as MO  # noqa: E402
+from oracle import make_golden as G  # noqa: E402
+
+FL = [3, 4] + [1] * 3
+CASES = {
+    # name: (hparam overrides, epoch, batch, bank/DA state preset)
+    "mmatch_r18_e0": (dict(model="resnet18", embedding_dim=512, img_size=64, field_lengths=FL, num_classes=5, batch_size=16), 0, 16, None),
+    "mmatch_r18_bank": (dict(model="resnet18", embedding_dim=512, img_size=64, field_lengths=FL, num_classes=5, batch_size=16, th1=0.25), 2, 16,
+                        dict(ptr=632, da_rows=3)),   # memory bank in use; 632 + 16 > 640: the enqueue is truncated to 8 samples
+    "mmatch_r18_binary": (dict(model="resnet18", embedding_dim=512, img_size=64, field_lengths=[4, 4] + [1] * 5, num_classes=2, batch_size=16,
+                               th1=0.55, target="CAD"), 3, 16, dict(ptr=100, da_rows=40)),
+}
+SCALARS = ["loss", "loss_ce", "loss_i_u", "loss_t_u"]
+TENSORS = ["y_hat_m", "y_hat_i", "y_hat_t", "x_m", "pseudo_label", "pseudo_label_orig", "mask1", "hard_idx"]
+
+
+def build_case(name):
+    over, epoch, B, preset = CASES[name]
+    hp = MO.default_hparams(**over)
+    sd = G.randomize_state(MO.init_state(hp, seed=5), seed=6)
+    sd = {k: v for k, v in sd.items() if not k.startswith("ema.")}  # MMatch keeps no EMA copy
+    g = torch.Generator().manual_seed(9)
+    K = hp.num_classes
+    if preset:
+        sd["embed_queue"] = torch.nn.functional.normalize(torch.randn(hp.projection_dim, MO.BANK, generator=g), dim=0)
+        sd["probs_queue"] = torch.softmax(torch.randn(K, MO.BANK, generator=g) * 2, dim=0)
+        sd["embed_queue_ptr"] = torch.tensor([preset["ptr"]])
+        sd["DA_queue"] = torch.zeros(256, K)
+        sd["DA_queue"][: preset["da_rows"]] = torch.softmax(torch.randn(preset["da_rows"], K, generator=g), dim=1)
+        sd["DA_ptr"] = torch.tensor([preset["da_rows"]])
+    else:
+        sd["embed_queue"] = torch.nn.functional.normalize(torch.randn(hp.projection_dim, MO.BANK, generator=g), dim=0)
+        sd["probs_queue"] = torch.zeros(K, MO.BANK)
+        sd["embed_queue_ptr"] = torch.zeros(1, dtype=torch.long)
+        sd["DA_queue"] = torch.zeros(256, K)
+        sd["DA_ptr"] = torch.zeros(1, dtype=torch.long)
+    batch = O.synthetic_batch(hp, B, seed=31)
+    if name == "mmatch_r18_bank":  # put the confidence threshold at the median so that mask1 is mixed
+        dry = MO.training_step({k: v.clone() for k, v in sd.items()}, batch, hp, epoch)
+        hp.th1 = float(dry["pseudo_label"].max(dim=1).values.median()) - 1e-4
+    return hp, sd, batch, epoch
+
+
+def run_reference(hp, sd, batch, epoch):
+    from models.SemiMultimodal.MMatch import MMatch
+    with tempfile.TemporaryDirectory() as td:
+        fl = os.path.join(td, "fl.pt")
+        torch.save(list(hp.field_lengths), fl)
+        model = MMatch(G.ref_hparams(hp, fl))
+    ref_keys = list(model.state_dict().keys())
+    assert ref_keys == list(sd.keys()), f"state_dict keys/order differ: {sorted(set(ref_keys) ^ set(sd.keys()))[:10]}"
+    model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    model.train()
+    model.current_epoch = epoch
+    cap = {}
+    fwd = model.forward
+
+    def forward(x):
+        out = fwd(x)
+        cap["out"] = out
+        return out
+
+    model.forward = forward
+    params = dict(model.named_parameters())
+    opt = torch.optim.Adam([{"params": model.model.parameters()}], lr=hp.lr_eval, weight_decay=hp.weight_decay_eval)
+    opt.zero_grad()
+    loss = model.training_step(batch, 0)
+    loss.backward()
+    grads = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in params.items()}
+    opt.step()
+    out = dict(loss=loss.detach(), loss_i_u=model.logged["multimodal.train.CEloss_unlabelled_i"].detach(),
+               loss_t_u=model.logged["multimodal.train.CEloss_unlabelled_t"].detach(),
+               y_hat_m=cap["out"][0].detach(), y_hat_i=cap["out"][1].detach(), y_hat_t=cap["out"][2].detach(), x_m=cap["out"][3].detach())
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.forward = fwd
+    model.eval()
+    x = [torch.cat((batch["l"][0][1], batch["u"][0][1])), torch.cat((batch["l"][1][1], batch["u"][1][1]))]
+    y = torch.cat((batch["l"][2], batch["u"][2]))
+    with torch.no_grad():
+        out["val_loss"] = model.validation_step((x, y), 0).detach()
+    return out, grads, state
+
+
+def install_mmatch_stubs():
+    """MMatch's backbone imports pl_bolts.utils.self_supervised.torchvision_ssl_encoder (lightning-bolts==0.5.0, absent
+    offline).  The reference vendors that very function and its ResNet as models/self_supervised.py + models/resnets.py
+    (used by the STiL backbone); the stub forwards to the vendored copy -- unpinned with respect to the pip package."""
+    import types
+    from models.self_supervised import torchvision_ssl_encoder
+    sys.modules["pl_bolts"].__path__ = []  # make the stub a package
+    m = types.ModuleType("pl_bolts.utils"); m.__path__ = []
+    sys.modules["pl_bolts.utils"] = m
+    m2 = types.ModuleType("pl_bolts.utils.self_supervised")
+    m2.torchvision_ssl_encoder = torchvision_ssl_encoder
+    sys.modules["pl_bolts.utils.self_supervised"] = m2
+
+
+def main():
+    sys.path.insert(0, G.REF)
+    G.install_stubs()
+    install_mmatch_stubs()
+    for name in CASES:
+        hp, sd, batch, epoch = build_case(name)
+        ref_out, ref_grads, ref_state = run_reference(hp, {k: v.clone() for k, v in sd.items()}, batch, epoch)
+        sd_o = {k: v.clone() for k, v in sd.items()}
+        o = MO.full_step(sd_o, {}, 1, batch, hp, epoch)
+        x_img = torch.cat((batch["l"][0][1], batch["u"][0][1])); x_tab = torch.cat((batch["l"][1][1], batch["u"][1][1]))
+        y_all = torch.cat((batch["l"][2], batch["u"][2]))
+        ov = MO.validation_step(sd_o, x_img, x_tab, y_all, hp)
+        o["val_loss"] = ov["loss"]
+        bad = []
+        for k, v in ref_out.items():
+            if not G.close(o[k].float(), v.float()):
+                bad.append((k, float((o[k].float() - v.float()).abs().max())))
+        for k, g in ref_grads.items():
+            go = o["grads"].get(k)
+            if g is None:
+                assert go is None or float(go.abs().max()) == 0.0, k
+            elif not G.close(go, g, tol=5e-5):
+                bad.append(("grad:" + k, float((go - g).abs().max())))
+        tr = set(MO.trainable_keys(sd))
+        for k, v in ref_state.items():
+            if k in tr:
+                if float((sd_o[k] - v).abs().max()) > 2.2 * hp.lr_eval:
+                    bad.append(("adam:" + k, float((sd_o[k] - v).abs().max())))
+            elif not G.close(sd_o[k].float(), v.float(), tol=2e-5):
+                bad.append(("state:" + k, float((sd_o[k].float() - v.float()).abs().max())))
+        assert not bad, f"[{name}] oracle != reference: {bad[:8]}"
+        # float64 yardstick for the gradients (see make_golden.py)
+        sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        b64 = {kk: ([t.double() for t in vv[0]], [t.double() for t in vv[1]], vv[2], vv[3].double(), vv[4]) for kk, vv in batch.items()}
+        o64 = MO.full_step(sd64, {}, 1, b64, hp, epoch)
+        fx = {"meta_epoch": np.int64(epoch)}
+        for k in SCALARS + ["val_loss"]:
+            fx["out_" + k] = (ref_out[k] if k in ref_out else o[k]).numpy().astype(np.float64)
+        for k in TENSORS:
+            fx["out_" + k] = (ref_out[k] if k in ref_out else o[k]).numpy()
+        for k, g in ref_grads.items():
+            fx["gnorm_" + k] = np.float64(0.0 if g is None else g.double().norm().item())
+            if g is not None:
+                g64 = o64["grads"][k]
+                fx["g64norm_" + k] = np.float64(g64.norm().item())
+                fx["gerr32_" + k] = np.float64(((g.double() - g64).norm() / (g64.norm() + 1e-30)).item())
+        for k in ("model.classifier_multimodal.weight", "model.classifier_tabular.weight", "model.encoder_imaging.conv1.weight"):
+            if ref_grads.get(k) is not None:
+                fx["grad_" + k] = ref_grads[k].numpy(); fx["grad64_" + k] = o64["grads"][k].numpy()
+        for k, v in ref_state.items():
+            if k in tr:
+                continue
+            if k in ("probs_queue", "embed_queue_ptr", "DA_ptr"):
+                fx["state_" + k] = v.numpy()
+            elif k in ("embed_queue", "DA_queue"):  # only the rows / columns this step wrote, plus a checksum of the rest
+                fx["ssum_" + k] = np.float64(v.double().sum().item()); fx["sabs_" + k] = np.float64(v.double().abs().sum().item())
+                if k == "embed_queue":
+                    p0 = int(sd["embed_queue_ptr"]); fx["state_embed_queue_cols"] = v[:, p0:p0 + 16].numpy()
+                else:
+                    fx["state_DA_queue_row"] = v[int(sd["DA_ptr"])].numpy()
+            else:
+                fx["ssum_" + k] = np.float64(v.double().sum().item()); fx["sabs_" + k] = np.float64(v.double().abs().sum().item())
+        path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+        np.savez_compressed(path, **fx)
+        print(f"{name}: oracle==reference OK  loss {float(ref_out['loss']):.6f}  mask1 {int(o['mask1'].sum())}/{len(o['mask1'])}  -> {os.path.getsize(path) / 1e3:.0f} kB")
+
+
+if __name__ == "__main__":
+    main()

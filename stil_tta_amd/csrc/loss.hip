@@ -507,3 +507,36 @@ extern "C" int stil_proto_commit(float* prototypes, float* prototypes_sum, float
   STIL_LAUNCH_CHECK();
   return STIL_OK;
 }
+
+
+// ---- hard pseudo-labels (MMatch.py:223-226): idx = argmax_k p (first maximum), mask = max >= th, one-hot row
+__global__ __launch_bounds__(64) void onehot_argmax_kernel(const float* __restrict__ p, int K, float th, float* __restrict__ onehot,
+                                                            float* __restrict__ roww, int* __restrict__ idx) {
+  const int row = blockIdx.x, lane = threadIdx.x;
+  const float* r = p + (long)row * K;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int j = lane; j < K; j += 64) {
+    const float v = r[j];
+    if (v > best) { best = v; bi = j; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  for (int j = lane; j < K; j += 64) onehot[(long)row * K + j] = (j == bi) ? 1.f : 0.f;
+  if (lane == 0) {
+    roww[row] = best >= th ? 1.f : 0.f;
+    idx[row] = bi;
+  }
+}
+
+extern "C" int stil_onehot_argmax(const float* probs, int rows, int K, float threshold, float* onehot, float* row_mask, int* idx,
+                                  void* stream) {
+  STIL_REQUIRE(probs && onehot && row_mask && idx && rows > 0 && K > 0, "stil_onehot_argmax: bad arguments");
+  hipLaunchKernelGGL(onehot_argmax_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, probs, K, threshold, onehot, row_mask, idx);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}

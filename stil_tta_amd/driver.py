@@ -73,7 +73,8 @@ def train_step(model, optimizer, batch, mask_random=None, mi_masks=None):
     """One optimisation step. Returns the (detached) loss tensor; no host sync."""
     sync_buffers(model)
     optimizer.zero_grad()
-    loss = model.training_step(batch, 0, mask_random=mask_random, mi_masks=mi_masks)
+    kw = {k: v for k, v in (('mask_random', mask_random), ('mi_masks', mi_masks)) if v is not None}  # STiL's injected randomness
+    loss = model.training_step(batch, 0, **kw)
     loss.backward()
     optimizer.grad_scale = allreduce_flat(model.flat.grads)
     optimizer.step()

@@ -94,3 +94,43 @@ def test_metrics_oracle_against_sklearn():
         assert abs(MO.topk_accuracy(z, yk, k) - top_k_accuracy_score(yk, z, k=k, labels=np.arange(K))) < 1e-12
     # degenerate class: no positives -> 0 (torchmetrics 0.11.0 rule, unpinned)
     assert MO.binary_auroc(s, np.zeros(500, bool)) == 0.0
+
+
+# ---------------------------------------------------------------- MMatch baseline
+from oracle import mmatch_oracle as MO  # noqa: E402
+from oracle import make_golden_mmatch as GM  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(GM.CASES))
+def test_mmatch_oracle_matches_reference_golden(name):
+    fx = np.load(os.path.join(GOLD, name + ".npz"))
+    hp, sd, batch, epoch = GM.build_case(name)
+    sd0 = {k: v.clone() for k, v in sd.items()}
+    out = MO.full_step(sd, {}, 1, batch, hp, epoch)
+    for k in GM.SCALARS:
+        assert _close(out[k].numpy(), fx["out_" + k], 2e-5), k
+    for k in GM.TENSORS:
+        a, b = out[k].numpy(), fx["out_" + k]
+        assert (np.array_equal(a, b) if b.dtype in (np.bool_, np.int64) else _close(a, b, 2e-5)), k
+    for key in fx.files:
+        if key.startswith("gnorm_"):
+            g = out["grads"].get(key[6:])
+            n = 0.0 if g is None else float(g.double().norm())
+            assert abs(n - float(fx[key])) <= 1e-4 * (1e-6 + float(fx[key])) + 1e-7, key
+        elif key.startswith("ssum_"):
+            assert abs(float(sd[key[5:]].double().sum()) - float(fx[key])) <= 2e-5 * (1.0 + float(fx["sabs_" + key[5:]])), key
+    p0 = int(sd0["embed_queue_ptr"])
+    assert _close(sd["embed_queue"][:, p0:p0 + 16].numpy(), fx["state_embed_queue_cols"], 2e-5)
+    assert _close(sd["probs_queue"].numpy(), fx["state_probs_queue"], 2e-5)
+    assert int(sd["embed_queue_ptr"].item()) == int(fx["state_embed_queue_ptr"].item()) and int(sd["DA_ptr"].item()) == int(fx["state_DA_ptr"].item())
+    assert _close(sd["DA_queue"][int(sd0["DA_ptr"])].numpy(), fx["state_DA_queue_row"], 2e-5)
+
+
+def test_mmatch_state_dict_layout():
+    from stil_tta_amd import MMatch
+    hp = MO.default_hparams(model="resnet18", embedding_dim=512, field_lengths=[3, 4, 1, 1, 1], num_classes=5, batch_size=16)
+    sd = MO.init_state(hp, seed=0)
+    m = MMatch(dict(vars(hp)))
+    got = m.state_dict()
+    assert list(got.keys()) == list(sd.keys())
+    assert all(tuple(got[k].shape) == tuple(sd[k].shape) for k in sd)
