@@ -115,10 +115,127 @@ def install_mmatch_stubs():
     sys.modules["pl_bolts.utils.self_supervised"] = m2
 
 
+CO_CASES = {
+    "cotrain_r18_eman": (dict(model="resnet18", embedding_dim=512, img_size=64, field_lengths=FL, num_classes=5, batch_size=16), 1, 16),
+    "cotrain_r18_noema": (dict(model="resnet18", embedding_dim=512, img_size=64, field_lengths=FL, num_classes=5, batch_size=16, use_ema=False), 1, 16),
+    "cotrain_r18_binary_paramema": (dict(model="resnet18", embedding_dim=512, img_size=64, field_lengths=[4, 4] + [1] * 5, num_classes=2, batch_size=16,
+                                         eman=False, target="CAD"), 2, 16),
+}
+CO_SCALARS = ["loss", "loss_ce", "loss_i_u", "loss_t_u"]
+CO_TENSORS = ["y_hat_m", "y_hat_i", "y_hat_t", "y_hat_i_e", "y_hat_t_e", "pseudo_label_i", "pseudo_label_t", "mask_i", "mask_t"]
+
+
+def build_co_case(name):
+    over, epoch, B = CO_CASES[name]
+    hp = MO.cotrain_hparams(**over)
+    sd = G.randomize_state(MO.cotrain_init_state(hp, seed=7), seed=8)   # randomize_state re-mirrors ema.* from model.*
+    if not hp.use_ema:
+        sd = {k: v for k, v in sd.items() if not k.startswith("ema.")}
+    else:  # a teacher that lags the student a little, so that the EMA arithmetic is visible
+        g = torch.Generator().manual_seed(3)
+        for k in sd:
+            if k.startswith("ema.") and sd[k].is_floating_point() and not k.endswith("running_var"):
+                sd[k] = sd[k] + 0.01 * torch.randn(sd[k].shape, generator=g) * (1.0 + sd[k].abs())
+    batch = O.synthetic_batch(hp, B, seed=41)
+    dry = MO.cotrain_training_step({k: v.clone() for k, v in sd.items()}, batch, hp, epoch)
+    both = torch.cat((dry["pseudo_label_i"].max(dim=1).values, dry["pseudo_label_t"].max(dim=1).values))
+    hp.co_threshold = float(both.median()) - 1e-4   # mixed confidence masks
+    return hp, sd, batch, epoch
+
+
+def run_co_reference(hp, sd, batch, epoch):
+    from models.SemiMultimodal.CoTraining import CoTraining
+    with tempfile.TemporaryDirectory() as td:
+        fl = os.path.join(td, "fl.pt")
+        torch.save(list(hp.field_lengths), fl)
+        model = CoTraining(G.ref_hparams(hp, fl))
+    ref_keys = list(model.state_dict().keys())
+    assert ref_keys == list(sd.keys()), f"state_dict keys/order differ: {sorted(set(ref_keys) ^ set(sd.keys()))[:10]}"
+    model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    model.train()
+    model.current_epoch = epoch
+    cap = {}
+    for nm, mod in (("s", model.model),) + ((("t", model.ema),) if hp.use_ema else ()):
+        f0 = mod.forward
+
+        def fwd(x, f0=f0, nm=nm):
+            out = f0(x)
+            cap[nm] = out
+            return out
+
+        mod.forward = fwd
+    params = {k: p for k, p in model.named_parameters() if k.startswith("model.")}
+    opt = torch.optim.Adam([{"params": model.model.parameters()}], lr=hp.lr_eval, weight_decay=hp.weight_decay_eval)
+    opt.zero_grad()
+    loss = model.training_step(batch, 0)
+    loss.backward()
+    grads = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in params.items()}
+    opt.step()
+    out = dict(loss=loss.detach(), loss_i_u=model.logged["multimodal.train.CEloss_unlabelled_i"].detach(),
+               loss_t_u=model.logged["multimodal.train.CEloss_unlabelled_t"].detach(),
+               y_hat_m=cap["s"][0].detach(), y_hat_i=cap["s"][1].detach(), y_hat_t=cap["s"][2].detach())
+    if hp.use_ema:
+        out["y_hat_i_e"], out["y_hat_t_e"] = cap["t"][1].detach(), cap["t"][2].detach()
+    return out, grads, {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+
+def co_main():
+    for name in CO_CASES:
+        hp, sd, batch, epoch = build_co_case(name)
+        ref_out, ref_grads, ref_state = run_co_reference(hp, {k: v.clone() for k, v in sd.items()}, batch, epoch)
+        sd_o = {k: v.clone() for k, v in sd.items()}
+        o = MO.cotrain_full_step(sd_o, {}, 1, batch, hp, epoch)
+        bad = []
+        for k, v in ref_out.items():
+            if not G.close(o[k].float(), v.float()):
+                bad.append((k, float((o[k].float() - v.float()).abs().max())))
+        for k, g in ref_grads.items():
+            go = o["grads"].get(k)
+            if g is None:
+                assert go is None or float(go.abs().max()) == 0.0, k
+            elif not G.close(go, g, tol=5e-5):
+                bad.append(("grad:" + k, float((go - g).abs().max())))
+        tr = set(MO.trainable_keys(sd))
+        for k, v in ref_state.items():
+            if k in tr:
+                if float((sd_o[k] - v).abs().max()) > 2.2 * hp.lr_eval:
+                    bad.append(("adam:" + k, float((sd_o[k] - v).abs().max())))
+            elif not G.close(sd_o[k].float(), v.float(), tol=2e-5):
+                bad.append(("state:" + k, float((sd_o[k].float() - v.float()).abs().max())))
+        assert not bad, f"[{name}] oracle != reference: {bad[:8]}"
+        sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        b64 = {kk: ([t.double() for t in vv[0]], [t.double() for t in vv[1]], vv[2], vv[3].double(), vv[4]) for kk, vv in batch.items()}
+        o64 = MO.cotrain_full_step(sd64, {}, 1, b64, hp, epoch)
+        fx = {"meta_epoch": np.int64(epoch), "meta_co_threshold": np.float64(hp.co_threshold)}
+        for k in CO_SCALARS:
+            fx["out_" + k] = (ref_out[k] if k in ref_out else o[k]).numpy().astype(np.float64)
+        for k in CO_TENSORS:
+            fx["out_" + k] = (ref_out[k] if k in ref_out else o[k]).numpy()
+        for k, g in ref_grads.items():
+            fx["gnorm_" + k] = np.float64(0.0 if g is None else g.double().norm().item())
+            if g is not None:
+                g64 = o64["grads"][k]
+                fx["g64norm_" + k] = np.float64(g64.norm().item())
+                fx["gerr32_" + k] = np.float64(((g.double() - g64).norm() / (g64.norm() + 1e-30)).item())
+        for k in ("model.classifier_imaging.weight", "model.classifier_tabular.weight", "model.encoder_imaging.conv1.weight"):
+            if ref_grads.get(k) is not None:
+                fx["grad_" + k] = ref_grads[k].numpy(); fx["grad64_" + k] = o64["grads"][k].numpy()
+        for k, v in ref_state.items():
+            if k not in tr:
+                fx["ssum_" + k] = np.float64(v.double().sum().item()); fx["sabs_" + k] = np.float64(v.double().abs().sum().item())
+        path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+        np.savez_compressed(path, **fx)
+        print(f"{name}: oracle==reference OK  loss {float(ref_out['loss']):.6f}  masks {int(o['mask_i'].sum())}+{int(o['mask_t'].sum())}/{len(o['mask_i'])}  -> {os.path.getsize(path) / 1e3:.0f} kB")
+
+
 def main():
     sys.path.insert(0, G.REF)
     G.install_stubs()
     install_mmatch_stubs()
+    if os.environ.get("ONLY") != "mmatch":
+        co_main()
+    if os.environ.get("ONLY") == "cotrain":
+        return
     for name in CASES:
         hp, sd, batch, epoch = build_case(name)
         ref_out, ref_grads, ref_state = run_reference(hp, {k: v.clone() for k, v in sd.items()}, batch, epoch)
@@ -150,7 +267,7 @@ def main():
         sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
         b64 = {kk: ([t.double() for t in vv[0]], [t.double() for t in vv[1]], vv[2], vv[3].double(), vv[4]) for kk, vv in batch.items()}
         o64 = MO.full_step(sd64, {}, 1, b64, hp, epoch)
-        fx = {"meta_epoch": np.int64(epoch)}
+        fx = {"meta_epoch": np.int64(epoch), "meta_th1": np.float64(hp.th1)}
         for k in SCALARS + ["val_loss"]:
             fx["out_" + k] = (ref_out[k] if k in ref_out else o[k]).numpy().astype(np.float64)
         for k in TENSORS:

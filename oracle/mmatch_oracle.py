@@ -66,9 +66,8 @@ def trainable_keys(sd):
     return out
 
 
-def backbone_forward(sd, x_img, x_tab, hp, train: bool):
+def backbone_forward(sd, x_img, x_tab, hp, train: bool, p: str = "model."):
     """MultimodalBackbone.forward (Multimodal_model.py:114-122): -> out_m, out_i, out_t, x_m."""
-    p = "model."
     x_i = O.resnet_forward(sd, p + "encoder_imaging.", x_img, hp.model, train).mean(dim=(2, 3))  # avgpool + flatten (resnets.py:266-267)
     x_t = O.tabular_forward(sd, p + "encoder_tabular.", x_tab, hp)
     cls = x_t[:, 0, :]
@@ -152,3 +151,68 @@ def validation_step(sd, x_img, x_tab, y, hp):
         loss_ce = F.cross_entropy(y_m, y)
         return dict(loss=hp.alpha * loss_ce, loss_ce=loss_ce, probs_m=torch.softmax(y_m, 1), probs_i=torch.softmax(y_i, 1),
                     probs_t=torch.softmax(y_t, 1))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CoTraining baseline ("CoTrain_Pseudo", models/SemiMultimodal/CoTraining.py): same backbone + EMA teacher; each
+# unimodal head learns from the OTHER modality's confident teacher distribution (soft cross-entropy).
+# State = model.* [+ ema.* when use_ema], no module-level buffers.
+# ------------------------------------------------------------------------------------------------------------------
+def cotrain_hparams(**over):
+    hp = O.default_hparams(alpha=0.2, rate_uce=0.2, start_epoch=0, use_ema=True, eman=True, ema_momentum=0.996)
+    hp.co_threshold = 0.9   # configs/config_dvm_CoTrain.yaml:160
+    for k, v in over.items():
+        setattr(hp, k, v)
+    return hp
+
+
+def cotrain_init_state(hp, seed: int = 0) -> Dict[str, Tensor]:
+    full = init_state(hp, seed)
+    sd = {k: v for k, v in full.items() if k.startswith("model.")}
+    if hp.use_ema:
+        for k in list(sd.keys()):
+            sd["ema." + k[len("model."):]] = sd[k].clone()
+    return sd
+
+
+def cotrain_training_step(sd, batch, hp, current_epoch: int) -> Dict[str, Tensor]:
+    """CoTraining.training_step (CoTraining.py:112-172)."""
+    im_l, tab_l, y_l = batch["l"][0][1], batch["l"][1][1], batch["l"][2]
+    im_u, tab_u = batch["u"][0][1], batch["u"][1][1]
+    B_l = len(y_l)
+    x_img, x_tab = torch.cat((im_l, im_u)), torch.cat((tab_l, tab_u))
+    y_m, y_i, y_t, _ = backbone_forward(sd, x_img, x_tab, hp, train=True)
+    with torch.no_grad():
+        if hp.use_ema:
+            O.ema_update(sd, hp.ema_momentum, hp.eman)
+            ym_e, yi_e, yt_e, _ = backbone_forward(sd, x_img, x_tab, hp, train=False, p="ema.")
+        else:
+            ym_e, yi_e, yt_e = y_m.detach().clone(), y_i.detach().clone(), y_t.detach().clone()
+    ce = F.cross_entropy
+    loss_ce = ce(y_m[:B_l], y_l) + ce(y_i[:B_l], y_l) + ce(y_t[:B_l], y_l)
+    pl_i = torch.softmax(yi_e[B_l:].detach(), dim=1)
+    pl_t = torch.softmax(yt_e[B_l:].detach(), dim=1)
+    mask_i = pl_i.max(dim=1).values.ge(hp.co_threshold)
+    mask_t = pl_t.max(dim=1).values.ge(hp.co_threshold)
+    loss_i_u = (ce(y_i[B_l:], pl_t, reduction="none") * mask_t).mean()
+    loss_t_u = (ce(y_t[B_l:], pl_i, reduction="none") * mask_i).mean()
+    loss = hp.alpha * loss_ce
+    if current_epoch > hp.start_epoch:
+        loss = loss + hp.rate_uce * (loss_i_u + loss_t_u)
+    return dict(loss=loss, loss_ce=loss_ce, loss_i_u=loss_i_u, loss_t_u=loss_t_u, y_hat_m=y_m, y_hat_i=y_i, y_hat_t=y_t,
+                y_hat_i_e=yi_e, y_hat_t_e=yt_e, pseudo_label_i=pl_i, pseudo_label_t=pl_t, mask_i=mask_i, mask_t=mask_t)
+
+
+def cotrain_full_step(sd, opt, step_idx, batch, hp, current_epoch, lr=None):
+    keys = trainable_keys(sd)
+    for k in keys:
+        sd[k].requires_grad_(True)
+    out = cotrain_training_step(sd, batch, hp, current_epoch)
+    gl = torch.autograd.grad(out["loss"], [sd[k] for k in keys], allow_unused=True)
+    for k in keys:
+        sd[k].requires_grad_(False)
+    grads = dict(zip(keys, gl))
+    O.adam_step(sd, grads, opt, step_idx, hp.lr_eval if lr is None else lr, hp.weight_decay_eval)
+    out = {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in out.items()}
+    out["grads"] = grads
+    return out

@@ -184,7 +184,7 @@ class MMatch(STiLModel):
         """MMatch.py:279-308."""
         x, y = batch
         self.setup_device()
-        dev = self.embed_queue.device
+        dev = self.prototypes.device
         y = y.to(dev)
         y_hat, y_i_hat, y_t_hat, _ = self.model.run((x[0].to(dev, torch.float32).contiguous(), x[1].to(dev, torch.float32).contiguous()), False)
         loss_ce = ops.CEHardFn.apply(y_hat.contiguous(), y)
@@ -202,9 +202,114 @@ class MMatch(STiLModel):
         """MMatch.py:343-355."""
         x, y = batch
         self.setup_device()
-        dev = self.embed_queue.device
+        dev = self.prototypes.device
         y_hat = self.model.run((x[0].to(dev, torch.float32).contiguous(), x[1].to(dev, torch.float32).contiguous()), False)[0]
         p = self._metric_probs(y_hat)
         self.acc_test(p, y.to(dev))
         self.auc_test(p, y.to(dev))
         return p
+
+
+class CoTraining(STiLModel):
+    """`CoTrain_Pseudo` baseline -- models/SemiMultimodal/CoTraining.py: the concatenation backbone plus an (optional) EMA
+    teacher of it; each unimodal head is trained on the OTHER modality's teacher distribution where that teacher is
+    confident (soft cross-entropy, CoTraining.py:141-149).  state_dict = model.* [+ ema.*]."""
+
+    def __init__(self, hparams):  # noqa: D401 -- not STiLModel.__init__ (different backbone, no module buffers)
+        _Base.__init__(self)
+        hp = _as_namespace(hparams)
+        hp.co_threshold = float(getattr(hp, "co_threshold", 0.9))
+        if _HAVE_PL:
+            self.save_hyperparameters(vars(hp))
+        else:
+            self.hparams = hp
+            self._epoch = 0
+            self.logged: Dict[str, torch.Tensor] = {}
+        self.hp = hp
+        fl = getattr(hp, "field_lengths", None)
+        if fl is None:
+            fl = torch.load(hp.field_lengths_tabular)
+        self.field_lengths = [int(v) for v in fl]
+        self.model = MultimodalBackbone(hp, self.field_lengths)
+        self.use_ema = bool(hp.use_ema)
+        if self.use_ema:  # CoTraining.py:43-51
+            self.ema = MultimodalBackbone(hp, self.field_lengths)
+            self.ema.load_state_dict(self.model.state_dict())
+            for q in self.ema.parameters():
+                q.requires_grad = False
+        self.initialize_metrics(hp.num_classes, hp.num_classes)
+        self.best_val_score = 0
+        self.flat: Optional[FlatState] = None
+        self.last: Dict[str, torch.Tensor] = {}
+
+    @property
+    def prototypes(self):  # device anchor used by the inherited helpers
+        return self.model.image_proj.weight
+
+    def setup_device(self, device=None):
+        if self.flat is not None:
+            return self
+        if lib().device_count() < 1:
+            raise RuntimeError("stil_tta_amd: no HIP device visible; the training step has no CPU path")
+        device = torch.device(device or "cuda")
+        nn.Module.to(self, device)
+        teacher = self.ema if self.use_ema else MultimodalBackbone(self.hp, self.field_lengths).to(device)
+        self.flat = FlatState(self.model, teacher, [], device)
+        return self
+
+    def forward(self, x):
+        return self.model.run(x, self.training)
+
+    def _confidence(self, probs, th):
+        """(max_k p >= th) as a 0/1 float row mask."""
+        R, K = probs.shape
+        dev = probs.device
+        onehot = torch.empty((R, K), dtype=torch.float32, device=dev)
+        mask = torch.empty((R,), dtype=torch.float32, device=dev)
+        idx = torch.empty((R,), dtype=torch.int32, device=dev)
+        lib().onehot_argmax(_p(probs), R, K, float(th), _p(onehot), _p(mask), _p(idx), _stream())
+        return mask
+
+    def training_step(self, batch, _=None):
+        hp = self.hp
+        self.setup_device()
+        dev = self.prototypes.device
+        im_l, tab_l, y_l = batch["l"][0][1], batch["l"][1][1], batch["l"][2]
+        im_u, tab_u, y_u = batch["u"][0][1], batch["u"][1][1], batch["u"][2]
+        B_l = len(y_l)
+        x = (torch.cat((im_l, im_u)).to(dev, torch.float32).contiguous(), torch.cat((tab_l, tab_u)).to(dev, torch.float32).contiguous())
+        y_l = y_l.to(dev)
+        y_m, y_i, y_t, _x = self.model.run(x, True)
+        with torch.no_grad():
+            if self.use_ema:  # CoTraining.py:128-133
+                self.flat.ema_update(hp.ema_momentum, bool(hp.eman))
+                _, yi_e, yt_e, _ = self.ema.run(x, False)
+            else:
+                yi_e, yt_e = y_i.detach(), y_t.detach()
+            pl_i = ops.softmax_rows(yi_e[B_l:].contiguous())
+            pl_t = ops.softmax_rows(yt_e[B_l:].contiguous())
+            mask_i, mask_t = self._confidence(pl_i, hp.co_threshold), self._confidence(pl_t, hp.co_threshold)
+        ce = ops.CEHardFn.apply
+        loss_ce = ce(y_m[:B_l].contiguous(), y_l) + ce(y_i[:B_l].contiguous(), y_l) + ce(y_t[:B_l].contiguous(), y_l)
+        loss_i_u = ops.CESoftFn.apply(y_i[B_l:].contiguous(), pl_t, mask_t)
+        loss_t_u = ops.CESoftFn.apply(y_t[B_l:].contiguous(), pl_i, mask_i)
+        loss = hp.alpha * loss_ce
+        if self.current_epoch > hp.start_epoch:
+            loss = loss + hp.rate_uce * (loss_i_u + loss_t_u)
+        with torch.no_grad():
+            if hp.train_metrics and not torch.cuda.is_current_stream_capturing():
+                prob_m = self._metric_probs(y_m)
+                y_u_dev = y_u.to(dev)
+                self.acc_train(prob_m[:B_l], y_l); self.auc_train(prob_m[:B_l], y_l)
+                self.acc_train_unlabelled(prob_m[B_l:], y_u_dev); self.auc_train_unlabelled(prob_m[B_l:], y_u_dev)
+        bs = B_l + len(y_u)
+        for name, v in (("CEloss", loss_ce), ("CEloss_unlabelled_i", loss_i_u), ("CEloss_unlabelled_t", loss_t_u), ("loss", loss)):
+            self.log(f"multimodal.train.{name}", v.detach(), on_epoch=True, on_step=False, batch_size=bs)
+        self.last = dict(loss=loss, loss_ce=loss_ce, loss_i_u=loss_i_u, loss_t_u=loss_t_u, y_hat_m=y_m, y_hat_i=y_i, y_hat_t=y_t,
+                         y_hat_i_e=yi_e, y_hat_t_e=yt_e, pseudo_label_i=pl_i, pseudo_label_t=pl_t, mask_i=mask_i, mask_t=mask_t)
+        return loss
+
+    training_epoch_end = MMatch.training_epoch_end
+    on_train_epoch_end = MMatch.training_epoch_end   # the reference uses the newer hook name (CoTraining.py:175)
+    validation_step = MMatch.validation_step
+    test_step = MMatch.test_step

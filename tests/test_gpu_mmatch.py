@@ -22,6 +22,7 @@ def test_mmatch_training_step_matches_reference_golden(name):
     from stil_tta_amd.flat import StilAdam
     fx = np.load(os.path.join(GOLD, name + ".npz"))
     hp, sd, batch, epoch = GM.build_case(name)
+    hp.th1 = float(fx["meta_th1"])  # the data-dependent threshold of the generating machine (CPU rounding differs across hosts)
     m = MMatch(dict(vars(hp)))
     assert list(m.state_dict().keys()) == list(sd.keys())
     m.load_state_dict({k: v.clone() for k, v in sd.items()})
@@ -84,3 +85,50 @@ def test_mmatch_training_step_matches_reference_golden(name):
     y = torch.cat((batch["l"][2], batch["u"][2])).cuda()
     ok, err = _close(m.validation_step((x, y)).cpu().numpy(), fx["out_val_loss"])
     assert ok, ("val_loss", err)
+
+
+@pytest.mark.parametrize("name", list(GM.CO_CASES))
+def test_cotraining_step_matches_reference_golden(name):
+    """CoTrain_Pseudo baseline (models/SemiMultimodal/CoTraining.py): EMA (state_dict or parameters only) / no EMA."""
+    from stil_tta_amd import CoTraining
+    from stil_tta_amd.driver import train_step
+    from stil_tta_amd.flat import StilAdam
+    fx = np.load(os.path.join(GOLD, name + ".npz"))
+    hp, sd, batch, epoch = GM.build_co_case(name)
+    hp.co_threshold = float(fx["meta_co_threshold"])  # data-dependent threshold of the generating machine
+    m = CoTraining(dict(vars(hp)))
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict({k: v.clone() for k, v in sd.items()})
+    m.setup_device("cuda"); m.train(); m.current_epoch = epoch
+    train_step(m, StilAdam(m.flat, lr=hp.lr_eval), _to_dev(batch))
+    torch.cuda.synchronize()
+    bad = []
+    for k in GM.CO_SCALARS + ["y_hat_m", "y_hat_i", "y_hat_t", "y_hat_i_e", "y_hat_t_e", "pseudo_label_i", "pseudo_label_t"]:
+        ok, err = _close(m.last[k].detach().cpu().numpy(), fx["out_" + k])
+        if not ok:
+            bad.append((k, err))
+    assert np.array_equal(m.last["mask_i"].cpu().numpy() > 0.5, fx["out_mask_i"]) and np.array_equal(m.last["mask_t"].cpu().numpy() > 0.5, fx["out_mask_t"])
+    params = dict(m.named_parameters())
+    for key in fx.files:
+        if not key.startswith("gnorm_"):
+            continue
+        pname = key[6:]
+        p = params[pname]
+        if "g64norm_" + pname not in fx.files:
+            assert not p._stil_touched, pname
+            continue
+        n64, e32 = float(fx["g64norm_" + pname]), float(fx["gerr32_" + pname])
+        if "grad64_" + pname in fx.files:
+            g64 = fx["grad64_" + pname].astype(np.float64)
+            eg = np.linalg.norm(p._gslot.cpu().double().numpy() - g64) / (np.linalg.norm(g64) + 1e-30)
+            if eg > 3 * e32 + 1e-2:
+                bad.append(("grad " + pname, eg, e32))
+        elif abs(float(p._gslot.double().norm()) - n64) > (3 * e32 + 1e-2) * n64 + 1e-7:
+            bad.append(("gnorm " + pname, float(p._gslot.double().norm()), n64))
+    msd = m.state_dict()
+    for key in fx.files:
+        if key.startswith("ssum_"):
+            v = msd[key[5:]].double()
+            if abs(float(v.sum()) - float(fx[key])) > 5e-5 * (1.0 + float(fx["sabs_" + key[5:]])):
+                bad.append(("state " + key[5:], float(v.sum()), float(fx[key])))
+    assert not bad, f"{len(bad)} mismatches, first: {bad[:8]}"

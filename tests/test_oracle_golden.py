@@ -105,6 +105,7 @@ from oracle import make_golden_mmatch as GM  # noqa: E402
 def test_mmatch_oracle_matches_reference_golden(name):
     fx = np.load(os.path.join(GOLD, name + ".npz"))
     hp, sd, batch, epoch = GM.build_case(name)
+    hp.th1 = float(fx["meta_th1"])  # the data-dependent threshold of the generating machine (CPU rounding differs across hosts)
     sd0 = {k: v.clone() for k, v in sd.items()}
     out = MO.full_step(sd, {}, 1, batch, hp, epoch)
     for k in GM.SCALARS:
@@ -134,3 +135,19 @@ def test_mmatch_state_dict_layout():
     got = m.state_dict()
     assert list(got.keys()) == list(sd.keys())
     assert all(tuple(got[k].shape) == tuple(sd[k].shape) for k in sd)
+
+
+@pytest.mark.parametrize("name", list(GM.CO_CASES))
+def test_cotraining_oracle_matches_reference_golden(name):
+    fx = np.load(os.path.join(GOLD, name + ".npz"))
+    hp, sd, batch, epoch = GM.build_co_case(name)
+    hp.co_threshold = float(fx["meta_co_threshold"])
+    out = MO.cotrain_full_step(sd, {}, 1, batch, hp, epoch)
+    for k in GM.CO_SCALARS:
+        assert _close(out[k].numpy(), fx["out_" + k], 2e-5), k
+    for k in GM.CO_TENSORS:
+        a, b = out[k].numpy(), fx["out_" + k]
+        assert (np.array_equal(a, b) if b.dtype == np.bool_ else _close(a, b, 2e-5)), k
+    for key in fx.files:
+        if key.startswith("ssum_"):
+            assert abs(float(sd[key[5:]].double().sum()) - float(fx[key])) <= 2e-5 * (1.0 + float(fx["sabs_" + key[5:]])), key
