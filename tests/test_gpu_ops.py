@@ -494,3 +494,59 @@ def test_geglu_rowsoftmax_matmul_nn(ops):
     od = ops.MatmulNNFn.apply(ops.RowSoftmaxFn.apply(sd_), vd)
     od.backward(dev(go))
     close(od, o); close(sd_.grad, s.grad, name="dlogits"); close(vd.grad, v.grad, name="dv")
+
+
+@pytest.mark.parametrize("M,C,tile_note", [(200, 64, "ragged last tile"), (64 * 37 + 5, 128, "many tiles"), (9000, 256, "two-stage combine"), (40, 64, "single partial tile")])
+def test_bn_statistics_two_pass_and_tile_paths_agree_with_float64(ops, M, C, tile_note):
+    """Training-mode BN statistics three ways: stil_bn_train_fwd (pilot-shifted two-pass), the per-tile Welford partials a
+    GEMM epilogue writes (stil_gemm_nt colstats -> stil_bn_train_fwd_tiles), and float64 -- on data whose mean dwarfs its
+    spread (|mean| / std = 50), where a naive E[x^2] - mean^2 in fp32 loses every digit."""
+    from stil_tta_amd._lib import lib
+    L = lib()
+    g = torch.Generator().manual_seed(M)
+    K = 32
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(C, K, generator=g) * 0.05
+    A[:, 0] = 50.0 / 0.05  # a constant input column: every output channel gets mean ~ 50 * W[c, 0] / 0.05, spread ~ 0.28
+    y64 = A.double() @ W.double().t()
+    mean64, var64 = y64.mean(0), y64.var(0, unbiased=False)
+    gam, bet = torch.ones(C), torch.zeros(C)
+    Ad, Wd, gd, bd = dev(A), dev(W), dev(gam), dev(bet)   # keep the device tensors alive across the raw C-ABI calls
+    outs = {}
+    for mode in ("tiles", "two_pass"):
+        rm, rv, nbt = dev(torch.zeros(C)), dev(torch.ones(C)), torch.zeros((), dtype=torch.long, device="cuda")
+        stats = torch.empty(4, C, device="cuda"); z = torch.empty(M, C, device="cuda")
+        if mode == "tiles":
+            T = L.gemm_nt_tile_rows(M, C)
+            ts = torch.empty(2 * ((M + T - 1) // T), C, device="cuda")
+            y = ops.gemm_nt(Ad, Wd, M, C, K, colstats=ts)
+            nb = L.bn_tiles_workspace_bytes(M, C, T)
+            ws = torch.empty(max(nb, 8), dtype=torch.uint8, device="cuda")
+            L.bn_train_fwd_tiles(y.data_ptr(), ts.data_ptr(), T, gd.data_ptr(), bd.data_ptr(), rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(),
+                                 None, z.data_ptr(), stats.data_ptr(), M, C, 0, 1e-5, 0.1, ws.data_ptr(), nb, None)
+        else:
+            y = ops.gemm_nt(Ad, Wd, M, C, K)
+            nb = L.bn_workspace_bytes(M, C)
+            ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+            L.bn_train_fwd(y.data_ptr(), gd.data_ptr(), bd.data_ptr(), rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(), None, z.data_ptr(),
+                           stats.data_ptr(), M, C, 0, 1e-5, 0.1, ws.data_ptr(), nb, None)
+        torch.cuda.synchronize()
+        outs[mode] = (stats.cpu(), z.cpu(), rm.cpu(), rv.cpu(), int(nbt))
+    for mode, (stats, z, rm, rv, nbt) in outs.items():
+        assert nbt == 1
+        assert float((stats[0].double() - mean64).abs().max() / mean64.abs().max()) < 5e-7, (mode, "mean")
+        rel = ((1.0 / stats[1].double() ** 2 - 1e-5) - var64).abs() / var64
+        assert float(rel.max()) < 2e-3, (mode, "variance", float(rel.max()))  # fp32 rounding of y itself: ulp(50) / 0.28
+        assert float((rm.double() - 0.1 * mean64).abs().max()) < 1e-4 * float(mean64.abs().max()), (mode, "running_mean")
+        zref = ((y64 - mean64) / (var64 + 1e-5).sqrt()).float()
+        assert float((z - zref).abs().max()) < 2e-2, (mode, "z")
+    assert float((outs["tiles"][1] - outs["two_pass"][1]).abs().max()) < 2e-3
+
+
+def test_onehot_argmax_first_maximum_and_threshold(ops):
+    from stil_tta_amd._lib import lib
+    p = torch.tensor([[0.2, 0.5, 0.5, 0.1], [0.9, 0.05, 0.03, 0.02], [0.25, 0.25, 0.25, 0.25]], device="cuda")
+    oh = torch.empty_like(p); mask = torch.empty(3, device="cuda"); idx = torch.empty(3, dtype=torch.int32, device="cuda")
+    lib().onehot_argmax(p.data_ptr(), 3, 4, 0.5, oh.data_ptr(), mask.data_ptr(), idx.data_ptr(), None)
+    assert idx.tolist() == [1, 0, 0] and mask.tolist() == [1.0, 1.0, 0.0]
+    assert torch.equal(oh.cpu(), torch.nn.functional.one_hot(torch.tensor([1, 0, 0]), 4).float())
