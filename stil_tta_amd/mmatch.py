@@ -12,6 +12,7 @@ from __future__ import annotations
 from typing import Dict, Optional
 
 import torch
+import torch.distributed as dist
 import torch.nn as nn
 
 from . import ops
@@ -154,13 +155,17 @@ class MMatch(STiLModel):
             # _dequeue_and_enqueue (MMatch.py:102-117): every sample of the batch, truncated at the end of the ring
             if self._ptr is None:
                 self._ptr = int(self.embed_queue_ptr)
-            n = min(B_l + B_u, BANK - self._ptr)
-            self.embed_queue[:, self._ptr:self._ptr + n] = feat_m[:n].t()
-            nl = min(B_l, n)
-            if nl > 0:
-                self.probs_queue[:, self._ptr:self._ptr + nl] = torch.nn.functional.one_hot(y_l[:nl], K).to(torch.float32).t()
-            if n > nl:
-                self.probs_queue[:, self._ptr + nl:self._ptr + n] = pseudo[: n - nl].t()
+            z = feat_m
+            t = torch.cat((torch.nn.functional.one_hot(y_l, K).to(torch.float32), pseudo), dim=0)   # pseudo_label_all (MMatch.py:243)
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:       # concat_all_gather (MMatch.py:104-106)
+                zs = [torch.empty_like(z) for _ in range(dist.get_world_size())]
+                ts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+                dist.all_gather(zs, z.contiguous())
+                dist.all_gather(ts, t.contiguous())
+                z, t = torch.cat(zs), torch.cat(ts)
+            n = min(z.shape[0], BANK - self._ptr)
+            self.embed_queue[:, self._ptr:self._ptr + n] = z[:n].t()
+            self.probs_queue[:, self._ptr:self._ptr + n] = t[:n].t()
             self._ptr = (self._ptr + n) % BANK
             self.embed_queue_ptr.fill_(self._ptr)
 
