@@ -191,7 +191,8 @@ def main():
                                global_batch=a.batch * world, parallelism=f"dp{world}", precision="fp32-exact MFMA",
                                launch="hipGraph replay" if a.graph else "eager",
                                input="host memory through data.DevicePrefetcher (PCIe-inclusive)" if a.host_input else "resident in HBM"),
-                   roofline=roof, loss=round(loss, 5))
+                   roofline=roof, loss=round(loss, 5),
+                   hbm_peak_gb=round(torch.cuda.max_memory_allocated(dev) / 1e9, 2), hbm_reserved_gb=round(torch.cuda.memory_reserved(dev) / 1e9, 2))
         if fps:
             out["step_tflops_algorithmic"] = round(value * fps / 1e12, 2)
             out["step_frac_of_fp32_mfma_peak"] = round(value * fps / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4)
