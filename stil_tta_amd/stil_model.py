@@ -139,6 +139,10 @@ class STiLModel(_Base):
         self.last: Dict[str, torch.Tensor] = {}
         if hp.checkpoint:
             self._load_tip_checkpoint(hp)
+        if hp.tabular_encoder == "saint" and getattr(hp, "checkpoint_SAINT", None):  # STiLModel_SAINT_backbone.py:144-146
+            self.model.encoder_tabular.load_state_dict(torch.load(hp.checkpoint_SAINT, map_location="cpu", weights_only=False))
+            if self.use_ema:
+                self.ema.load_state_dict(self.model.state_dict())
 
     # ------------------------------------------------------------------ plumbing
     if not _HAVE_PL:
@@ -181,9 +185,14 @@ class STiLModel(_Base):
 
     def _load_tip_checkpoint(self, hp):
         """STiLModel_backbone.py:69-90,108-115: load encoder_imaging.* / encoder_tabular.* from a TIP checkpoint."""
-        ck = torch.load(hp.checkpoint, map_location="cpu")
+        ck = torch.load(hp.checkpoint, map_location="cpu", weights_only=False)
         sd = ck["state_dict"]
-        for mod, prefix in ((self.model.encoder_imaging, "encoder_imaging."), (self.model.encoder_tabular, "encoder_tabular.")):
+        if hp.pretrained_model != "TIP":
+            raise ValueError(f"Unknown pretrain model: {hp.pretrained_model}")  # STiLModel_backbone.py:89-90
+        pairs = [(self.model.encoder_imaging, "encoder_imaging.")]
+        if hp.tabular_encoder != "saint":  # the SAINT backbone takes only the image encoder from TIP (STiLModel_SAINT_backbone.py:74-76)
+            pairs.append((self.model.encoder_tabular, "encoder_tabular."))
+        for mod, prefix in pairs:
             sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix) and "projection_head" not in k and "prototypes" not in k}
             mod.load_state_dict(sub, strict=True)
             if hp.finetune_strategy == "frozen":

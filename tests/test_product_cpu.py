@@ -148,3 +148,39 @@ def test_fit_host_helpers():
     bc = F.BestCheckpoint("eval.val.acc", "/tmp/x", "checkpoint_best_acc")
     assert bc.path == "/tmp/x/checkpoint_best_acc.ckpt"
     assert [bc.improved(v, e) for e, v in enumerate((0.1, 0.1, 0.3, 0.2))] == [True, False, True, False] and bc.best_epoch == 2
+
+
+def test_checkpoint_loading_tip_and_saint(tmp_path):
+    """hparams.checkpoint (TIP: encoder_imaging.* [+ encoder_tabular.* for the Transformer backbone], frozen / trainable) and
+    hparams.checkpoint_SAINT (a bare SAINT state_dict) -- STiLModel_backbone.py:69-90, STiLModel_SAINT_backbone.py:68-90,144-146."""
+    import torch
+    from stil_tta_amd import STiLModel
+    fl = [3, 4, 1, 1, 1]
+    base = dict(model="resnet18", embedding_dim=512, field_lengths=fl, num_classes=5, batch_size=8)
+    torch.manual_seed(1)
+    src = STiLModel(dict(base))
+    tip = {"state_dict": {k[len("model."):]: (v.clone() + 0.5 if v.is_floating_point() else v.clone() + 3) for k, v in src.state_dict().items()
+                          if k.startswith("model.encoder_imaging.") or k.startswith("model.encoder_tabular.")}, "hyper_parameters": {}}
+    tip["state_dict"]["encoder_tabular.projection_head.weight"] = torch.zeros(1)  # ignored keys (STiLModel_backbone.py:111)
+    pt = tmp_path / "tip.ckpt"
+    torch.save(tip, pt)
+    torch.manual_seed(2)
+    m = STiLModel(dict(base, checkpoint=str(pt), finetune_strategy="frozen"))
+    sd = m.state_dict()
+    for k, v in tip["state_dict"].items():
+        if "projection_head" not in k:
+            assert torch.equal(sd["model." + k], v) and torch.equal(sd["ema." + k], v), k
+    assert not any(p.requires_grad for p in m.model.encoder_imaging.parameters()) and not any(p.requires_grad for p in m.model.encoder_tabular.parameters())
+    assert all(p.requires_grad for p in m.model.projection_si.parameters())
+    # SAINT: image encoder from TIP, tabular encoder from checkpoint_SAINT
+    torch.manual_seed(3)
+    s0 = STiLModel(dict(base, tabular_encoder="saint"))
+    saint_sd = {k: (v.clone() + 1 if v.is_floating_point() else v.clone()) for k, v in s0.model.encoder_tabular.state_dict().items()}
+    ps = tmp_path / "saint.pth"
+    torch.save(saint_sd, ps)
+    torch.manual_seed(4)
+    s1 = STiLModel(dict(base, tabular_encoder="saint", checkpoint=str(pt), checkpoint_SAINT=str(ps)))
+    got = s1.state_dict()
+    for k, v in saint_sd.items():
+        assert torch.equal(got["model.encoder_tabular." + k], v) and torch.equal(got["ema.encoder_tabular." + k], v), k
+    assert torch.equal(got["model.encoder_imaging.conv1.weight"], tip["state_dict"]["encoder_imaging.conv1.weight"])
