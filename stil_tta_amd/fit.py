@@ -240,7 +240,11 @@ def fit(model, train_loaders: Dict[str, Iterable], val_loader: Optional[Iterable
                 stopped = "early_stopping"
                 break
         if sched is not None:
-            sched.step()
+            if isinstance(sched, torch.optim.lr_scheduler.ReduceLROnPlateau):  # scheduler: linear (monitors the validation metric)
+                if last_val:
+                    sched.step(last_val[ckpt.monitor])
+            else:
+                sched.step()
     if world_size() > 1:
         dist.barrier()
     return dict(best_score=ckpt.best, best_epoch=ckpt.best_epoch, checkpoint=ckpt.path, epochs_run=epoch + 1 - start_epoch if max_epochs > start_epoch else 0,

@@ -41,6 +41,7 @@ _DEFAULTS = dict(
     batch_size=512, lr_eval=1e-4, weight_decay_eval=0.0, scheduler="anneal", warmup_epochs=10, max_epochs=500,
     checkpoint=None, pretrained_model="TIP", finetune_strategy="trainable", pretrain=False, logdir=None,
     mi_dropout=True, seed=2022, train_metrics=True,
+    lr=3e-4, cosine_anneal_mult=1, dataset_length=1, check_val_every_n_epoch=1,  # only read by scheduler: cosine / linear
     tabular_encoder="transformer",  # "saint": the STiLModel_SAINT.py variant (also selected by algorithm_name == "STiL_SAINT")
 )
 
@@ -219,11 +220,19 @@ class STiLModel(_Base):
         """STiLModel.py:557-577: Adam(lr_eval, weight_decay_eval) over model + projectors + CLUBs (EMA excluded)."""
         self.setup_device(self.prototypes.device if self.prototypes.is_cuda else None)
         opt = StilAdam(self.flat, lr=self.hp.lr_eval, weight_decay=self.hp.weight_decay_eval)
-        if self.hp.scheduler == "anneal":
+        hp = self.hp
+        if hp.scheduler == "anneal":  # STiLModel.py:582-583 (pl_bolts LinearWarmupCosineAnnealingLR, closed form)
             from .driver import anneal_lambda
-            sched = torch.optim.lr_scheduler.LambdaLR(opt, anneal_lambda(self.hp.warmup_epochs, self.hp.max_epochs))
-            return {"optimizer": opt, "lr_scheduler": sched}
-        return {"optimizer": opt}
+            sched = torch.optim.lr_scheduler.LambdaLR(opt, anneal_lambda(hp.warmup_epochs, hp.max_epochs))
+        elif hp.scheduler == "cosine":  # STiLModel.py:580-581
+            sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=int(hp.dataset_length * hp.cosine_anneal_mult), eta_min=0, last_epoch=-1)
+        elif hp.scheduler == "linear":  # STiLModel.py:584-585
+            sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, patience=int(10 / hp.check_val_every_n_epoch), min_lr=hp.lr * 0.0001)
+        elif hp.scheduler in (None, "none"):  # the repo's own tests: constant learning rate
+            return {"optimizer": opt}
+        else:
+            raise ValueError('Valid schedulers are "cosine" and "anneal"')  # STiLModel.py:587
+        return {"optimizer": opt, "lr_scheduler": sched}
 
     def project_3features(self, feat_m=None, feat_i=None, feat_t=None):  # STiLModel.py:182-192
         fm = ops.l2norm(self.projector_multimodal.run(feat_m)) if feat_m is not None else None
