@@ -119,6 +119,7 @@ class MMatch(STiLModel):
         im_l, tab_l, y_l = batch["l"][0][1], batch["l"][1][1], batch["l"][2]
         im_u, tab_u, y_u = batch["u"][0][1], batch["u"][1][1], batch["u"][2]
         B_l, B_u = len(y_l), len(y_u)
+        self._check_identify(batch)                                                              # MMatch.py:199-200
         K, T = hp.num_classes, float(hp.temperature)
         x_img = torch.cat((im_l, im_u)).to(dev, torch.float32).contiguous()
         x_tab = torch.cat((tab_l, tab_u)).to(dev, torch.float32).contiguous()
@@ -282,6 +283,7 @@ class CoTraining(STiLModel):
         im_l, tab_l, y_l = batch["l"][0][1], batch["l"][1][1], batch["l"][2]
         im_u, tab_u, y_u = batch["u"][0][1], batch["u"][1][1], batch["u"][2]
         B_l = len(y_l)
+        self._check_identify(batch)                                                              # CoTraining.py:121-122
         x = (torch.cat((im_l, im_u)).to(dev, torch.float32).contiguous(), torch.cat((tab_l, tab_u)).to(dev, torch.float32).contiguous())
         y_l = y_l.to(dev)
         y_m, y_i, y_t, _x = self.model.run(x, True)

@@ -263,6 +263,15 @@ class STiLModel(_Base):
         lib().da_apply(_p(probs), _p(qmean), _p(out), Bu, K, _stream())
         return out
 
+    def _check_identify(self, batch):
+        """STiLModel.py:237-238: the 'l' part is all labelled, the 'u' part all unlabelled.  Flags already on the device are
+        checked on the first step only (the reference's assert is a host sync per step)."""
+        il, iu = batch["l"][4], batch["u"][4]
+        if torch.is_tensor(il) and torch.is_tensor(iu) and (not il.is_cuda or not getattr(self, "_identify_checked", False)):
+            assert int(il.sum()) == len(il), "batch['l'] contains unlabelled samples"
+            assert int(iu.sum()) == 0, "batch['u'] contains labelled samples"
+            self._identify_checked = True
+
     def _mi_masks(self, B, mi_masks):
         dev = self.prototypes.device
         saint = self.hp.tabular_encoder == "saint"
@@ -301,6 +310,7 @@ class STiLModel(_Base):
         im_u, tab_u, y_u = batch["u"][0][1], batch["u"][1][1], batch["u"][2]
         B_l, B_u = len(y_l), len(y_u)
         B = B_l + B_u
+        self._check_identify(batch)
         x_img = torch.cat((im_l, im_u)).to(dev, torch.float32).contiguous()
         x_tab = torch.cat((tab_l, tab_u)).to(dev, torch.float32).contiguous()
         y_l = y_l.to(dev)

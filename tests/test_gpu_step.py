@@ -250,6 +250,20 @@ def test_bench_shape_properties():
     assert torch.equal(loss, loss2) and torch.equal(g1, m2.flat.grads)
 
 
+def test_mislabelled_parts_are_rejected():
+    """STiLModel.py:237-238: batch['l'] must be all labelled, batch['u'] all unlabelled."""
+    from stil_tta_amd import STiLModel
+    from stil_tta_amd.driver import synthetic_batch
+    fl = [3, 4] + [1] * 3
+    m = STiLModel(dict(model="resnet18", embedding_dim=512, field_lengths=fl, num_classes=5, batch_size=16))
+    m.setup_device("cuda"); m.train()
+    b = synthetic_batch(fl, 5, 16, 64, seed=1, device="cuda")
+    im, tab, y, orig, ident = b["u"]
+    bad = dict(b, u=(im, tab, y, orig, torch.ones_like(ident)))
+    with pytest.raises(AssertionError):
+        m.training_step(bad, 0)
+
+
 def test_empty_and_ragged_inputs_fail_loudly():
     from stil_tta_amd import ops
     x = torch.randn(4, 8)
