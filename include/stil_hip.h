@@ -200,6 +200,10 @@ int stil_proto_add(const float* class_sum_cnt, float* prototypes_sum, float* pro
 int stil_proto_commit(float* prototypes, float* prototypes_sum, float* prototypes_count_sum,
                       int* bad_count_dev, int K, int Dp, void* stream);
 
+/* logged partition ratios (STiLModel.py:307-311) from cgpl_pgls's flags [rows,ld] = (case id 1..4, mask1, ...):
+ * out5 = {threshold1_ratio, case1_ratio, case2_i_ratio, case2_t_ratio, case3_ratio} */
+int stil_flag_ratios(const unsigned char* flags, int ld, int rows, float* out5, void* stream);
+
 /* hard pseudo-labels of the MMatch baseline (models/SemiMultimodal/MMatch.py:223-226): onehot[r] = e_argmax(probs[r]) (first
  * maximum), row_mask[r] = (max >= threshold) as 0/1 floats, idx[r] = the argmax */
 int stil_onehot_argmax(const float* probs, int rows, int K, float threshold, float* onehot, float* row_mask, int* idx,

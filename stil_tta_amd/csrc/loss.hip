@@ -540,3 +540,32 @@ extern "C" int stil_onehot_argmax(const float* probs, int rows, int K, float thr
   STIL_LAUNCH_CHECK();
   return STIL_OK;
 }
+
+
+// ---- logged partition ratios (STiLModel.py:307-311): out = {mean(mask1), mean(case == 1), .. == 2, .. == 3, .. == 4}
+// flags: [rows, ld] bytes, columns (CGPL case id 1..4, mask1, ...) as written by cgpl_pgls_kernel.  One block, fixed order.
+__global__ __launch_bounds__(256) void flag_ratios_kernel(const unsigned char* __restrict__ flags, int ld, int rows, float* __restrict__ out) {
+  __shared__ int sh[5][4];
+  int c[5] = {0, 0, 0, 0, 0};
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    const int cs = flags[(long)r * ld], m1 = flags[(long)r * ld + 1];
+    c[0] += m1 != 0;
+    c[1] += cs == 1; c[2] += cs == 2; c[3] += cs == 3; c[4] += cs == 4;
+  }
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    int v = c[q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[q][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) out[threadIdx.x] = (float)(sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3]) / (float)rows;
+}
+
+extern "C" int stil_flag_ratios(const unsigned char* flags, int ld, int rows, float* out5, void* stream) {
+  STIL_REQUIRE(flags && out5 && rows > 0 && ld >= 2, "stil_flag_ratios: bad arguments");
+  hipLaunchKernelGGL(flag_ratios_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, flags, ld, rows, out5);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}

@@ -410,8 +410,13 @@ class STiLModel(_Base):
                 self.acc_train_unlabelled(prob_m[B_l:], y_u_dev)
                 self.auc_train_unlabelled(prob_m[B_l:], y_u_dev)
 
+            ratios = torch.empty(5, dtype=torch.float32, device=dev)                               # STiLModel.py:307-311
+            lib().flag_ratios(_p(flags), flags.shape[1], B_u, _p(ratios), _stream())
+
         lib().counter_inc(_p(self._rng_step), _stream())
         bs = B
+        for j, name in enumerate(("threshold1_ratio", "case1_ratio", "case2_i_ratio", "case2_t_ratio", "case3_ratio")):
+            self.log(f"multimodal.train.{name}", ratios[j], on_epoch=True, on_step=False, batch_size=bs)
         for name, v in (("CEloss", loss_ce), ("CEloss_unlabelled_m", loss_m_u), ("CEloss_unlabelled_i", loss_i_u),
                         ("CEloss_unlabelled_t", loss_t_u), ("ITCloss", loss_itc), ("CLUBloss_imaging", club_i),
                         ("CLUBloss_imaging_est", est_i), ("CLUBloss_tabular", club_t), ("CLUBloss_tabular_est", est_t),

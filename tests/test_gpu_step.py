@@ -168,6 +168,9 @@ def test_two_steps_match_oracle_dvm_native_shape():
             if not ok:
                 bad.append((step, k, err))
         _check_flags(m.last, o, 14)
+        for nm, ref in (("threshold1_ratio", o["mask1"]), ("case1_ratio", o["case1"]), ("case2_i_ratio", o["case2_i"]),
+                        ("case2_t_ratio", o["case2_t"]), ("case3_ratio", o["case3"])):   # logged like STiLModel.py:307-311
+            assert abs(float(m.logged["multimodal.train." + nm]) - float(ref.float().mean())) < 1e-6, nm
         params = _named_params(m)
         ratios = []
         for k, gr in o["grads"].items():
