@@ -179,7 +179,7 @@ class MMatch(STiLModel):
 
     def training_epoch_end(self, _=None):
         """MMatch.py:265-276: epoch metrics only (no prototypes to commit)."""
-        if self.hp.train_metrics and self.acc_train.counts is not None:
+        if self.hp.train_metrics and self.auc_train.preds:  # something was accumulated this epoch
             for name, met in (("eval.train.acc", self.acc_train), ("eval.train.auc", self.auc_train),
                               ("eval.train_unlabelled.acc", self.acc_train_unlabelled), ("eval.train_unlabelled.auc", self.auc_train_unlabelled)):
                 self.log(name, met.compute(), on_epoch=True, on_step=False)

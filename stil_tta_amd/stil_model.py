@@ -434,7 +434,7 @@ class STiLModel(_Base):
     def training_epoch_end(self, _=None):
         """STiLModel.py:389-421: prototypes <- sum / count (every class needs a confident sample), zero accumulators."""
         K, Dp = self.hp.num_classes, self.hp.projection_dim
-        if self.hp.train_metrics and self.acc_train.counts is not None:  # STiLModel.py:393-405
+        if self.hp.train_metrics and self.auc_train.preds:  # something was accumulated this epoch  # STiLModel.py:393-405
             vals = {}
             for name, met in (("eval.train.acc", self.acc_train), ("eval.train.auc", self.auc_train),
                               ("eval.train_unlabelled.acc", self.acc_train_unlabelled), ("eval.train_unlabelled.auc", self.auc_train_unlabelled)):

@@ -198,7 +198,23 @@ def test_two_steps_match_oracle_dvm_native_shape():
         assert not bad, f"{len(bad)} mismatches, first: {bad[:10]}"
         # keep both sides on identical parameters so step 2 tests the step, not Adam's noise amplification
         m.load_state_dict({k: v.clone() for k, v in sd.items()})
-    O.training_epoch_end(sd) if bool((sd["prototypes_count_sum"] >= 1).all()) else None
+    # epoch end (STiLModel.py:408-415): prototypes <- class sums / counts; needs a confident sample of every class, which
+    # 2 x 16 samples over 286 classes cannot give: seed the accumulators of the missing classes identically on both sides
+    g2 = torch.Generator().manual_seed(99)
+    add_sum = torch.randn(hp.num_classes, hp.projection_dim, generator=g2)
+    missing = (sd["prototypes_count_sum"] < 1).float()
+    sd["prototypes_sum"] += add_sum * missing
+    sd["prototypes_count_sum"] += 2.0 * missing
+    m.prototypes_sum.copy_(sd["prototypes_sum"].cuda()); m.prototypes_count_sum.copy_(sd["prototypes_count_sum"].cuda())
+    O.training_epoch_end(sd)
+    m.training_epoch_end()
+    ok, err = _close(m.prototypes.cpu().numpy(), sd["prototypes"].numpy(), 2e-5)
+    assert ok, ("prototypes after epoch end", err)
+    assert float(m.prototypes_sum.abs().sum()) == 0.0 and float(m.prototypes_count_sum.abs().sum()) == 0.0
+    m.prototypes_count_sum[3] = 0.0  # a class without a confident sample must trip the reference's assert (STiLModel.py:412)
+    m.prototypes_count_sum[:3] = 1.0; m.prototypes_count_sum[4:] = 1.0
+    with pytest.raises(AssertionError):
+        m.training_epoch_end()
 
 
 def test_bench_shape_properties():
