@@ -360,6 +360,8 @@ def test_side_stream_pipeline_is_bit_exact():
     ("img96_batch6", dict(field_lengths=[3, 1, 1], img_size=96), 6),          # B_l = 1, B_u = 5: ragged tiles everywhere
     ("img100_not_multiple_of_32", dict(field_lengths=[3, 1, 1], img_size=100), 8),
     ("three_classes_more_samples_than_tile", dict(field_lengths=[4, 1], num_classes=3), 72),  # M crosses a 64-row tile
+    ("no_ema_teacher", dict(field_lengths=[3, 1, 1], use_ema=False), 8),                          # STiLModel.py:254-257: teacher = student
+    ("distribution_alignment_on", dict(field_lengths=[3, 1, 1], DA=True), 8),
 ])
 def test_edge_layouts_match_oracle(label, over, B):
     """Column layouts / image sizes / batch sizes the reference's modules accept (empty categorical or continuous part,
@@ -371,6 +373,8 @@ def test_edge_layouts_match_oracle(label, over, B):
     base.update(over)
     hp = O.default_hparams(**base)
     sd = randomize_state(O.init_state(hp, seed=11), seed=12)
+    if not hp.use_ema:  # the reference module then has no `ema` child (STiLModel.py:83-91)
+        sd = {k: v for k, v in sd.items() if not k.startswith("ema.")}
     g = torch.Generator().manual_seed(13)
     sd["prototypes"] = torch.nn.functional.normalize(torch.randn(hp.num_classes, hp.projection_dim, generator=g))
     m = _make_model(hp, {k: v.clone() for k, v in sd.items()})
