@@ -403,3 +403,34 @@ def test_edge_layouts_match_oracle(label, over, B):
             if not ok:
                 bad.append(("state " + k, err))
     assert not bad, f"{label}: {len(bad)} mismatches, first: {bad[:8]}"
+
+
+def test_frozen_encoders_are_not_updated():
+    """finetune_strategy == 'frozen' (STiLModel_backbone.py:78-84): the encoders take no gradient and Adam leaves them alone,
+    while their BatchNorm layers still run in training mode (batch statistics, running buffers move) as in the reference."""
+    from stil_tta_amd import STiLModel
+    from stil_tta_amd.driver import synthetic_batch, train_step
+    from stil_tta_amd.flat import StilAdam
+    fl = [3, 4] + [1] * 3
+    torch.manual_seed(0)
+    m = STiLModel(dict(model="resnet18", embedding_dim=512, field_lengths=fl, num_classes=5, start_epoch=0, batch_size=16, th1=0.3))
+    for mod in (m.model.encoder_imaging, m.model.encoder_tabular):
+        for p in mod.parameters():
+            p.requires_grad = False
+    m.setup_device("cuda"); m.train(); m.current_epoch = 1
+    m.prototypes.copy_(torch.nn.functional.normalize(torch.randn(5, 128, generator=torch.Generator().manual_seed(1))).cuda())
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    train_step(m, StilAdam(m.flat, lr=1e-2), synthetic_batch(fl, 5, 16, 64, seed=3, device="cuda"))
+    torch.cuda.synchronize()
+    after = m.state_dict()
+    moved_head = False
+    for k, v in after.items():
+        if k.startswith("model.encoder_"):
+            if k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"):
+                continue
+            assert torch.equal(v, before[k]), f"frozen parameter {k} changed"
+        elif k.startswith("model.projection_si") and k.endswith("weight"):
+            moved_head = moved_head or not torch.equal(v, before[k])
+    assert moved_head
+    assert not torch.equal(after["model.encoder_imaging.bn1.running_mean"], before["model.encoder_imaging.bn1.running_mean"])
+    assert all(not p._stil_touched for p in m.model.encoder_imaging.parameters())
