@@ -362,6 +362,7 @@ def test_side_stream_pipeline_is_bit_exact():
     ("three_classes_more_samples_than_tile", dict(field_lengths=[4, 1], num_classes=3), 72),  # M crosses a 64-row tile
     ("no_ema_teacher", dict(field_lengths=[3, 1, 1], use_ema=False), 8),                          # STiLModel.py:254-257: teacher = student
     ("distribution_alignment_on", dict(field_lengths=[3, 1, 1], DA=True), 8),
+    ("repeat_ratio_3", dict(field_lengths=[3, 1, 1], repeat_ratio=3.0), 16),                      # trainers/evaluate.py:83 -> STiLModel.py:222-224
 ])
 def test_edge_layouts_match_oracle(label, over, B):
     """Column layouts / image sizes / batch sizes the reference's modules accept (empty categorical or continuous part,
