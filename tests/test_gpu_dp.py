@@ -83,3 +83,40 @@ def test_two_rank_step_equals_sum_of_shards():
     scale = float(gsum.abs().max())
     assert float((r0["grads"] - gsum).abs().max()) <= 1e-6 * (1 + scale)
     assert float((r0["psum"] - psum).abs().max()) <= 1e-5 and torch.equal(r0["pcnt"], pcnt)
+
+
+def _nccl_worker(port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)  # "nccl" is RCCL on ROCm
+    m, opt = _make()
+    flat = m.flat
+    flat.grads.normal_()
+    ref = flat.grads.clone()
+    works = [dist.all_reduce(flat.grads[o:o + (8 << 20)], op=dist.ReduceOp.SUM, async_op=True) for o in range(0, flat.total, 8 << 20)]
+    for w in works:
+        w.wait()
+    for slab in flat.buffer_slabs():
+        dist.broadcast(slab, src=0)
+    cs = torch.ones(5, 129, device="cuda")
+    dist.all_reduce(cs)
+    dist.barrier()
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(flat.grads, ref)) and float(cs.sum()) == 5 * 129
+    open(os.path.join(outdir, "ok"), "w").write("1" if ok else "0")
+    dist.destroy_process_group()
+
+
+def test_rccl_collectives_accept_the_slab_views():
+    """The exact collective calls of the data-parallel step (bucketed all-reduce of gradient-slab slices, broadcast of the
+    buffer ranges, the fused prototype all-reduce, barrier) on the RCCL backend; a one-rank group is all one GPU allows,
+    which still exercises RCCL's initialisation, stream hand-over and the tensor views it is given."""
+    with tempfile.TemporaryDirectory() as td:
+        ctx = mp.get_context("spawn")
+        p = ctx.Process(target=_nccl_worker, args=(29900 + os.getpid() % 90, td))
+        p.start()
+        p.join(timeout=300)
+        assert p.exitcode == 0
+        assert open(os.path.join(td, "ok")).read() == "1"
