@@ -70,10 +70,15 @@ class _Lib:
             fn.argtypes = [t for t, _ in argl]
         self._dll.stil_last_error.restype = ctypes.c_char_p
         self._prof = None
+        self._prof_single = True
 
     # ---- optional per-entry-point GPU timing (HIP events on the launch stream); used by bench.py only
-    def begin_profile(self):
+    def begin_profile(self, single_stream: bool = True):
+        """single_stream: keep every launch on the caller's stream while profiling (clean per-kernel durations); False lets
+        the side stream run as usual, events then bracket each launch on whichever stream it goes to (durations include
+        the time a kernel shares the chip with the other stream's kernel)."""
         self._prof = []
+        self._prof_single = bool(single_stream)
 
     def end_profile(self):
         import torch

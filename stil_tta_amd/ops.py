@@ -161,7 +161,8 @@ def wgrad_param(param, dY, X, M, N, K, **kw):
 
 
 def _prof_active():
-    return lib()._prof is not None  # per-entry-point timing brackets launches with events on ONE stream
+    L = lib()
+    return L._prof is not None and L._prof_single  # single-stream profiling: keep every launch on the caller's stream
 
 
 def colsum(X, out, M, N, *, ld=None, accumulate=0, scale=1.0):
