@@ -132,12 +132,12 @@ def main():
         if feed:
             batch = next(feed)
         if s == a.steps - 2 and not a.graph:
-            L.begin_profile(single_stream=False)  # second-to-last step: events around every launch, both streams running
+            L.begin_profile(single_stream=False, only=("gemm_nt",))  # second-to-last step: events around the GEMM launches, both streams running
         if s == a.steps - 1:
             if prof_conc is None and L._prof is not None:
                 torch.cuda.synchronize()
                 prof_conc = L.end_profile()
-            L.begin_profile()  # HIP events around every C-ABI launch of the last timed step (same stream)
+            L.begin_profile(only=None if a.breakdown else ("gemm_nt", "wgrad_tn"))  # HIP events around the launches of the last timed step (one stream)
         if a.graph and s == a.steps - 1:
             eager_step(m, opt, batch)  # per-launch events need eager launches: the profiled last step runs eagerly
         else:

@@ -71,14 +71,16 @@ class _Lib:
         self._dll.stil_last_error.restype = ctypes.c_char_p
         self._prof = None
         self._prof_single = True
+        self._prof_only = None
 
     # ---- optional per-entry-point GPU timing (HIP events on the launch stream); used by bench.py only
-    def begin_profile(self, single_stream: bool = True):
+    def begin_profile(self, single_stream: bool = True, only=None):
         """single_stream: keep every launch on the caller's stream while profiling (clean per-kernel durations); False lets
         the side stream run as usual, events then bracket each launch on whichever stream it goes to (durations include
         the time a kernel shares the chip with the other stream's kernel)."""
         self._prof = []
         self._prof_single = bool(single_stream)
+        self._prof_only = None if only is None else frozenset(only)  # entry points to bracket (None = all)
 
     def end_profile(self):
         import torch
@@ -98,7 +100,7 @@ class _Lib:
 
         def call(*args, meta=None):
             prof = self.__dict__.get("_prof")
-            if prof is not None:
+            if prof is not None and (self._prof_only is None or name in self._prof_only):
                 import torch
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
