@@ -80,10 +80,6 @@ def main():
     from stil_tta_amd.flat import StilAdam
 
     rank, world, local = init_distributed()
-    for env, setter in (("STIL_WGRAD_VARIANT", "set_wgrad_variant"), ("STIL_GEMM_VARIANT", "set_gemm_variant"),
-                        ("STIL_GEMM_BK", "set_gemm_bk")):
-        if os.environ.get(env):  # A/B knobs for in-situ tile experiments (cold caches, real neighbours)
-            getattr(lib(), setter)(int(os.environ[env]))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path in the product)"
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)

@@ -8,7 +8,7 @@
  * Conventions
  *   - all tensors fp32, contiguous unless a leading dimension (ld*) is given; device pointers;
  *   - caller owns every buffer (PyTorch allocator); the library allocates nothing and keeps
- *     no mutable global state apart from a one-time kernel attribute;
+ *     no mutable global state apart from a one-time kernel attribute (tuning choices are per-call arguments);
  *   - every call only ENQUEUES work on `stream` (a hipStream_t), never synchronises;
  *   - return 0 = ok, <0 = error (-1 invalid argument, -2 unsupported shape, -3 HIP error);
  *     stil_last_error() returns the thread-local message; nothing throws across the boundary;
@@ -46,22 +46,23 @@ int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, 
                  int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad_y, int pad_x,
                  int mode, int out_stride, int out_py, int out_px, int out_OH, int out_OW,
                  const float* bias, const float* sub, const float* scale, const float* shift, const float* resid,
-                 int ldr, float* pre, int act, float alpha, float* colstats, void* stream);
-int stil_gemm_nt_tile_rows(int M, int N);
-
-/* tile variant stil_gemm_nt launches for an [M,N] output: 22 = 128x128, 21 = 128x64, 11 = 64x64 (bench bookkeeping) */
-int stil_gemm_nt_variant(int M, int N);
-/* tuning knob for A/B measurements: K-depth of the NT kernel's LDS tile (16 or 32; default 32) */
-int stil_set_gemm_bk(int bk);
-int stil_set_gemm_variant(int v);
-int stil_set_wgrad_variant(int v);
+                 int ldr, float* pre, int act, float alpha, float* colstats, int tune, void* stream);
+/* `tune` (0 = automatic; otherwise for A/B measurements) = variant + 100 * bk32 + 1000 * acc2:
+ *   variant  block tile: 22 = 128x128, 21 = 128x64, 11 = 64x64 (0: chosen from M, N);
+ *   bk32     1 = 32-deep LDS k-tiles instead of 16;
+ *   acc2     two-level accumulation (partial chains of 64 products added to a master accumulator, ~ATen-CPU's
+ *            rounding noise for long reductions): 0 = for K >= 512, 1 = never, 2 = always.
+ * rows per output tile / tile variant stil_gemm_nt uses for an [M,N] output under `tune` (colstats granularity, bench bookkeeping) */
+int stil_gemm_nt_tile_rows(int M, int N, int tune);
+int stil_gemm_nt_variant(int M, int N, int tune);
 
 /* Weight gradient  dW (+)= dY[M,N]^T . Xgather[M,K]  (split over M, slab partials + ordered reduce).
- * KH*KW > 1: dW is written in the reference layout (N, srcC, KH, KW); else [N, Kdst] (first Kdst columns). */
-size_t stil_wgrad_workspace_bytes(int M, int N, int K);
+ * KH*KW > 1: dW is written in the reference layout (N, srcC, KH, KW); else [N, Kdst] (first Kdst columns).
+ * `tune`: 0 = automatic block tile, 22 = 128x128 (64x128 for N <= 64), 11 = 64x64 (same value for the workspace query). */
+size_t stil_wgrad_workspace_bytes(int M, int N, int K, int tune);
 int stil_wgrad_tn(const float* dY, const float* X, float* dW, int M, int N, int K, int ldy, int ldx,
                   int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad,
-                  int Kdst, int accumulate, float* workspace, size_t workspace_bytes, void* stream);
+                  int Kdst, int accumulate, float* workspace, size_t workspace_bytes, int tune, void* stream);
 
 /* out[n] (+)= scale * sum_m X[m,n]   (bias gradients) */
 size_t stil_colsum_workspace_bytes(int M, int N);

@@ -239,6 +239,8 @@ TENSORS = ["y_hat_m", "y_hat_i", "y_hat_t", "x_si_enhance", "x_si", "x_ai", "x_s
            "feat_m", "feat_i", "feat_t", "y_hat_m_e", "y_hat_i_e", "y_hat_t_e", "feat_m_e", "pseudo_label_orig",
            "pseudo_label", "prediction", "case1", "case2_i", "case2_t", "case3", "mask1", "mask_random",
            "class_sum", "class_count"]
+# locals of the reference's training_step read back from its frame (see run_reference)
+LOCALS = ["pseudo_label_orig", "prediction", "case1", "case2_i", "case2_t", "case3", "mask1", "mask_random", "loss_pt"]
 FULL_GRADS = ["model.encoder_tabular.simple_MLP.1.layers.0.weight", "model.encoder_tabular.embeds.weight",
               "model.encoder_tabular.pos_encodings.weight", "model.encoder_tabular.transformer.layers.0.2.fn.fn.to_out.bias",
               "model.encoder_tabular.transformer.layers.0.1.fn.fn.net.3.weight", "model.classifier_multimodal.weight", "model.reduce.bias", "model.encoder_tabular.cls_token",
@@ -340,7 +342,31 @@ def run_reference(hp, sd, batch, epoch, mask_random, mi_masks):
 
         model.model.forward_all, model.ema.forward_all, model.project_3features = wrap_s, wrap_e, wrap_p3
         ps0, pc0 = model.prototypes_sum.clone(), model.prototypes_count_sum.clone()
-        loss = model.training_step(batch, 0)
+        # CGPL / PGLS intermediates are locals of the reference's training_step (STiLModel.py:259-299): read them from
+        # its frame when it returns (a profile hook: nothing in the reference is edited), and take `pseudo_label`
+        # (re-bound to one column for K = 2 before the return, STiLModel.py:353) from the soft-target cross_entropy call.
+        import torch.nn.functional as RF
+        orig_ce, orig_profile = RF.cross_entropy, sys.getprofile()
+        step_code = type(model).training_step.__code__
+
+        def ce_spy(inp, target, *a, **k):
+            if target.is_floating_point() and k.get("reduction") == "none":
+                cap.setdefault("pseudo_label", target.detach().clone())
+            return orig_ce(inp, target, *a, **k)
+
+        def prof(frame, event, arg):
+            if event == "return" and frame.f_code is step_code:
+                loc = frame.f_locals
+                for nm in LOCALS:
+                    cap["loc_" + nm] = loc[nm].detach().clone()
+
+        RF.cross_entropy = ce_spy
+        sys.setprofile(prof)
+        try:
+            loss = model.training_step(batch, 0)
+        finally:
+            sys.setprofile(orig_profile)
+            RF.cross_entropy = orig_ce
         loss.backward()
         grads = {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in model.named_parameters()
                  if not k.startswith("ema.")}
@@ -374,6 +400,9 @@ def run_reference(hp, sd, batch, epoch, mask_random, mi_masks):
     out["y_hat_m_e"], out["y_hat_i_e"], out["y_hat_t_e"] = e[0].detach(), e[1].detach(), e[2].detach()
     out["feat_m"], out["feat_i"], out["feat_t"] = (t.detach() for t in cap["p3"][0])
     out["feat_m_e"] = cap["p3"][1][0].detach()
+    for nm in LOCALS:  # the reference's own pseudo-labels, case masks and threshold mask
+        out[nm] = cap["loc_" + nm]
+    out["pseudo_label"] = cap["pseudo_label"]
     out["class_sum"] = model.prototypes_sum - ps0
     out["class_count"] = model.prototypes_count_sum - pc0
     out.update(val)
@@ -381,12 +410,19 @@ def run_reference(hp, sd, batch, epoch, mask_random, mi_masks):
     return out, grads, {k: v.detach().clone() for k, v in model.state_dict().items()}
 
 
-def run_oracle64(hp, sd, batch, epoch, mask_random, mi_masks):
-    """The oracle's full step in float64 (ground truth for gradient conditioning)."""
+def run_oracle64(hp, sd, batch, epoch, mask_random, mi_masks, decisions=None):
+    """The oracle's full step in float64 (ground truth for gradient conditioning).  decisions = (relu, pool) dicts:
+    replay those ReLU signs / max-pool winners instead of deciding anew (stil_oracle.force_decisions); the tally of
+    units that float64 would have decided differently comes back as out["flips"]."""
     f64 = torch.float64
     s = {k: (v.clone().to(f64) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     b = {k: ([v[0][0].to(f64), v[0][1].to(f64)], [v[1][0].to(f64), v[1][1].to(f64)], v[2], v[3].to(f64), v[4]) for k, v in batch.items()}
-    return O.full_step(s, {}, 1, b, hp, epoch, mask_random, mi_masks)
+    if decisions is None:
+        return O.full_step(s, {}, 1, b, hp, epoch, mask_random, mi_masks)
+    with O.force_decisions(*decisions) as d:
+        out = O.full_step(s, {}, 1, b, hp, epoch, mask_random, mi_masks)
+    out["flips"] = d.get("flips", {})
+    return out
 
 
 def close(a, b, tol=2e-5):
@@ -443,12 +479,11 @@ def main():
         # ---- store the reference's numbers
         fx = {"meta_epoch": np.int64(epoch)}
         for k in SCALARS:
-            fx["out_" + k] = (ref_out[k] if k in ref_out else o[k]).numpy().astype(np.float64)
+            fx["out_" + k] = ref_out[k].numpy().astype(np.float64)
         for k in VAL_KEYS:
             fx["out_" + k] = ref_out[k].numpy()
         for k in TENSORS:
-            v = ref_out[k] if k in ref_out else o[k]  # masks / pseudo-labels are internal to training_step: oracle values, implied-checked via the losses + class_sum
-            fx["out_" + k] = v.numpy()
+            fx["out_" + k] = ref_out[k].numpy()  # every tensor is the REFERENCE's (CGPL / PGLS internals read from its frame)
         # Conditioning: the same step in float64.  Deep train-mode-BN backward amplifies fp32 rounding (the
         # reference's own fp32 gradients sit up to ~2e-2 relative L2 away from the fp64 truth in these cases), so
         # every gradient is stored with gerr32 = relL2(reference fp32, fp64): the GPU path must be as close to the

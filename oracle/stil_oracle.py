@@ -341,27 +341,90 @@ def _bn(sd, name, x, train: bool):
                         sd[name + ".weight"], sd[name + ".bias"], training=train, momentum=0.1, eps=1e-5)
 
 
+# Piecewise-linear decisions of the STUDENT pass (ReLU signs, max-pool winners).  Two fp32 evaluations of the same
+# network can land on different sides of a kink when a pre-activation sits within rounding of 0, and every gradient
+# upstream of that unit then differs by O(1) of its contribution although both runs are right.  The gradient parity
+# tests therefore run the float64 oracle ON THE DEVICE'S DECISIONS: `record_decisions()` collects the oracle's own,
+# `force_decisions(d)` replays the ones exported by the HIP path (tags = reference module names; missing tags fall
+# back to the oracle's own decision).
+_DEC: Optional[dict] = None
+
+
+class record_decisions:
+    def __enter__(self):
+        global _DEC
+        self.prev, _DEC = _DEC, {"mode": "record", "relu": {}, "pool": {}}
+        return _DEC
+
+    def __exit__(self, *a):
+        global _DEC
+        _DEC = self.prev
+
+
+class force_decisions(record_decisions):
+    def __init__(self, relu: Dict[str, Tensor], pool: Dict[str, Tensor]):
+        self.d = {"mode": "force", "relu": relu, "pool": pool}
+
+    def __enter__(self):
+        global _DEC
+        self.prev, _DEC = _DEC, self.d
+        return _DEC
+
+
+def _relu(x: Tensor, tag: str) -> Tensor:
+    if _DEC is None or not tag.startswith("model."):
+        return F.relu(x)
+    if _DEC["mode"] == "force" and tag in _DEC["relu"]:
+        m = _DEC["relu"][tag]
+        assert m.shape == x.shape, (tag, m.shape, x.shape)
+        dis = (x.detach() > 0) != m  # units on which this evaluation would have decided differently
+        _DEC.setdefault("flips", {})[tag] = (int(dis.sum()), float(x.detach()[dis].abs().max()) if bool(dis.any()) else 0.0,
+                                              float(x.detach().abs().max()))
+        return x * m.to(x.dtype)
+    if _DEC["mode"] == "record":
+        _DEC["relu"][tag] = (x.detach() > 0)
+    return F.relu(x)
+
+
+def _max_pool(x: Tensor, tag: str) -> Tensor:
+    """nn.MaxPool2d(3, 2, 1) (models/resnets.py:252); decisions = flat input index iy*W+ix of every window's winner."""
+    if _DEC is None or not tag.startswith("model."):
+        return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    if _DEC["mode"] == "force" and tag in _DEC["pool"]:
+        idx = _DEC["pool"][tag]
+        y = x.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
+        own = F.max_pool2d(x.detach(), kernel_size=3, stride=2, padding=1)
+        _DEC.setdefault("flips", {})[tag] = (int((own != y.detach()).sum()), float((own - y.detach()).abs().max()), float(own.abs().max()))
+        return y
+    y, idx = F.max_pool2d(x, kernel_size=3, stride=2, padding=1, return_indices=True)
+    if _DEC["mode"] == "record":
+        _DEC["pool"][tag] = idx
+    return y
+
+
 def resnet_forward(sd, p, x, model: str, train: bool) -> Tensor:
     """models/resnets.py:248-260 with return_all_feature_maps=True; returns the last map."""
     kind, layers = resnet_spec(model)
     x = F.conv2d(x, sd[p + "conv1.weight"], stride=2, padding=3)
-    x = F.relu(_bn(sd, p + "bn1", x, train))
-    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    x = _relu(_bn(sd, p + "bn1", x, train), p + "bn1")
+    x = _max_pool(x, p + "maxpool")
     for li, nblk in enumerate(layers, start=1):
         for bi in range(nblk):
             stride = 2 if (bi == 0 and li > 1) else 1
             q = f"{p}layer{li}.{bi}."
             identity = x
             if kind == "bottleneck":  # models/resnets.py:112-132
-                out = F.relu(_bn(sd, q + "bn1", F.conv2d(x, sd[q + "conv1.weight"]), train))
-                out = F.relu(_bn(sd, q + "bn2", F.conv2d(out, sd[q + "conv2.weight"], stride=stride, padding=1), train))
+                out = _relu(_bn(sd, q + "bn1", F.conv2d(x, sd[q + "conv1.weight"]), train), q + "bn1")
+                out = _relu(_bn(sd, q + "bn2", F.conv2d(out, sd[q + "conv2.weight"], stride=stride, padding=1), train), q + "bn2")
                 out = _bn(sd, q + "bn3", F.conv2d(out, sd[q + "conv3.weight"]), train)
+                last = q + "bn3"
             else:  # models/resnets.py:71-88
-                out = F.relu(_bn(sd, q + "bn1", F.conv2d(x, sd[q + "conv1.weight"], stride=stride, padding=1), train))
+                out = _relu(_bn(sd, q + "bn1", F.conv2d(x, sd[q + "conv1.weight"], stride=stride, padding=1), train), q + "bn1")
                 out = _bn(sd, q + "bn2", F.conv2d(out, sd[q + "conv2.weight"], padding=1), train)
+                last = q + "bn2"
             if (q + "downsample.0.weight") in sd:
                 identity = _bn(sd, q + "downsample.1", F.conv2d(x, sd[q + "downsample.0.weight"], stride=stride), train)
-            x = F.relu(out + identity)
+            x = _relu(out + identity, last)  # the block's closing ReLU is tagged by its last BatchNorm
     return x
 
 
@@ -403,7 +466,7 @@ def tabular_forward(sd, p, x, hp) -> Tensor:
 
 def _mlp2(sd, p, x):
     """STiLModel_backbone.py:19-32  Linear -> ReLU -> Linear."""
-    return F.linear(F.relu(F.linear(x, sd[p + "model.0.weight"], sd[p + "model.0.bias"])),
+    return F.linear(_relu(F.linear(x, sd[p + "model.0.weight"], sd[p + "model.0.bias"]), p + "model.0"),
                     sd[p + "model.2.weight"], sd[p + "model.2.bias"])
 
 
@@ -503,11 +566,12 @@ def backbone_forward_all(sd, p, x_img, x_tab, hp, train: bool, masks=None):
     return out_m, out_i, out_t, e_si, x_si.mean(1), x_ai, e_st, x_st.mean(1), x_at, e_c
 
 
-def _head(sd, p, x):
-    """projection heads (STiLModel.py:56-63): nn.Linear or SimCLR head (Linear-ReLU-Linear)."""
+def _head(sd, p, x, student: bool = True):
+    """projection heads (STiLModel.py:56-63): nn.Linear or SimCLR head (Linear-ReLU-Linear).
+    student=False: the teacher's pass through the same head (no gradient, its ReLU is not a tracked decision)."""
     if (p + "weight") in sd:
         return F.linear(x, sd[p + "weight"], sd[p + "bias"])
-    h = F.relu(F.linear(x, sd[p + "layers.0.weight"], sd[p + "layers.0.bias"]))
+    h = _relu(F.linear(x, sd[p + "layers.0.weight"], sd[p + "layers.0.bias"]), ("model.:" if student else "teacher.:") + p + "layers.0")
     return F.linear(h, sd[p + "layers.2.weight"], sd[p + "layers.2.bias"])
 
 
@@ -522,7 +586,7 @@ def clip_loss(f0, f1, T, lam0):
 
 def club_forward(sd, p, x, y):
     """CLUBMean.forward (club.py:107-121) + learning_loss (club.py:125-130)."""
-    mu = F.linear(F.relu(F.linear(x, sd[p + "p_mu.0.weight"], sd[p + "p_mu.0.bias"])), sd[p + "p_mu.2.weight"], sd[p + "p_mu.2.bias"])
+    mu = F.linear(_relu(F.linear(x, sd[p + "p_mu.0.weight"], sd[p + "p_mu.0.bias"]), "model.:" + p + "p_mu.0"), sd[p + "p_mu.2.weight"], sd[p + "p_mu.2.bias"])
     positive = (-(mu - y) ** 2 / 2.0).sum(-1)
     negative = (-((y.unsqueeze(0) - mu.unsqueeze(1)) ** 2).mean(dim=1) / 2.0).sum(-1)
     club = (positive - negative).mean()
@@ -598,7 +662,7 @@ def training_step(sd: Dict[str, Tensor], batch, hp, current_epoch: int,
         if hp.use_ema:
             ema_update(sd, hp.ema_momentum, hp.eman)
             t_out = backbone_forward_all(sd, "ema.", x_img, x_tab, hp, train=False)
-            feat_m_e = F.normalize(_head(sd, "projector_multimodal.", torch.cat((t_out[3], t_out[9], t_out[6]), dim=1)))
+            feat_m_e = F.normalize(_head(sd, "projector_multimodal.", torch.cat((t_out[3], t_out[9], t_out[6]), dim=1), student=False))
             ym_e, yi_e, yt_e = t_out[0], t_out[1], t_out[2]
         else:
             t_out = tuple(t.detach() for t in s_out)

@@ -77,7 +77,12 @@ __device__ __forceinline__ float4 ld4_sel(const float* p, const float* safe, boo
   return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-template <int TM, int TN, int BK, bool VEC>
+// ACC2: two-level accumulation.  v_mfma_f32_32x32x2_f32 is an exact fp32 fmaf chain, so a K-long reduction done in ONE
+// accumulator carries ~sqrt(K) eps of rounding noise -- measured 5x ATen-CPU's error at K = 4608 (oneDNN keeps many
+// partial sums).  With ACC2 the MFMAs of FLUSH consecutive k-tiles (64 products) chain into a partial accumulator that
+// is then added to the master one: noise ~ (8 + sqrt(K/64)) eps, at the cost of 16 VGPRs per 32x32 tile and 16 v_add
+// per 32 MFMAs.  Used for K >= 512 (shorter reductions gain nothing).
+template <int TM, int TN, int BK, bool VEC, bool ACC2 = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
   constexpr int BM = 64 * TM, BN = 64 * TN, LS = BK + 4;   // LS = 20 / 36: conflict-free ds_read_b128 (i*LS mod 64 distinct)
   constexpr int KQ = BK / 4, RP = 256 / KQ;                 // float4 per tile row, tile rows per load pass
@@ -177,6 +182,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  constexpr int FLUSH = 64 / BK;   // k-tiles per partial chain (ACC2)
 
   const int nk = ntaps * ((g.C + BK - 1) / BK);
   // Interior fast path (block-uniform): single-tap gathers (plain GEMM, 1x1 conv) whose tile lies fully inside M x N
@@ -195,12 +201,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
         gload();
       }
     };
-    load();
-    lstore(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      const int buf = kt & 1;
-      if (kt + 1 < nk) load();
+    // the MFMAs of one k-tile into c; `fresh`: c starts from 0 (inline constant, no zeroed registers)
+    auto compute = [&](int buf, f32x16 (&c)[TM][TN], auto fresh_tag) {
+      constexpr bool FRESH = decltype(fresh_tag)::value;
       const float* Ab = As + buf * BM * LS + (wm * TM * 32 + li) * LS + lh * 4;
       const float* Bb = Bs + buf * BN * LS + (wn * TN * 32 + li) * LS + lh * 4;
 #pragma unroll
@@ -215,15 +218,61 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+            if (FRESH && t == 0) {
+              const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+              c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, zero, 0, 0, 0);
+            } else {
+              c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, c[i][j], 0, 0, 0);
+            }
+            c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, c[i][j], 0, 0, 0);
+            c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, c[i][j], 0, 0, 0);
+            c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, c[i][j], 0, 0, 0);
           }
         __builtin_amdgcn_s_setprio(0);
       }
-      if (kt + 1 < nk) lstore(buf ^ 1);
-      __syncthreads();
+    };
+    load();
+    lstore(0);
+    __syncthreads();
+    if constexpr (!ACC2) {
+      for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load();
+        compute(buf, acc, std::false_type{});
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+      }
+    } else {
+      int kt = 0;
+      for (; kt + FLUSH <= nk; kt += FLUSH) {   // FLUSH is even: the LDS buffer of tile kt + u is u & 1
+        f32x16 part[TM][TN];
+#pragma unroll
+        for (int u = 0; u < FLUSH; ++u) {
+          if (kt + u + 1 < nk) load();
+          if (u == 0) compute(0, part, std::true_type{}); else compute(u & 1, part, std::false_type{});
+          if (kt + u + 1 < nk) lstore((u & 1) ^ 1);
+          __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] += part[i][j];
+      }
+      if (kt < nk) {   // remainder (< FLUSH tiles): one more partial chain
+        f32x16 part[TM][TN];
+        const int kt0 = kt;
+        for (; kt < nk; ++kt) {
+          const int buf = kt & 1;
+          if (kt + 1 < nk) load();
+          if (kt == kt0) compute(buf, part, std::true_type{}); else compute(buf, part, std::false_type{});
+          if (kt + 1 < nk) lstore(buf ^ 1);
+          __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] += part[i][j];
+      }
     }
   };
   if (full) mainloop(std::true_type{}); else mainloop(std::false_type{});
@@ -511,32 +560,23 @@ static int check_geom(const ConvGeom& g, int vec_required) {
 
 static inline int is_vec(const void* p, int ld) { return (((uintptr_t)p) % 16 == 0) && (ld % 4 == 0); }
 
-static int g_gemm_bk = 16;
-// tuning knob (A/B measurements only): K-depth of the NT kernel's LDS tile, 16 or 32
-extern "C" int stil_set_gemm_bk(int bk) {
-  if (bk != 16 && bk != 32) { stil_set_error("stil_set_gemm_bk: %d not in {16, 32}", bk); return STIL_EINVAL; }
-  g_gemm_bk = bk;
-  return STIL_OK;
-}
 static bool g_nt_attr = false;
 static int gemm_nt_attr() {
   if (g_nt_attr) return STIL_OK;
-  hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<2, 2, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<2, 2, 32, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_kernel<2, 2, 32, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   if (e != hipSuccess) { stil_set_error("gemm_nt: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return STIL_EHIP; }
   g_nt_attr = true;
   return STIL_OK;
 }
 
-// which tile variant stil_gemm_nt launches for an [M,N] output: 22 = 128x128, 21 = 128x64, 11 = 64x64 block tile
-static int g_force_variant = 0;
-// tuning knob (A/B measurements only): force the tile variant (11, 21, 22) or 0 = automatic
-extern "C" int stil_set_gemm_variant(int v) {
-  if (v != 0 && v != 11 && v != 21 && v != 22) { stil_set_error("stil_set_gemm_variant: bad variant %d", v); return STIL_EINVAL; }
-  g_force_variant = v;
-  return STIL_OK;
-}
-extern "C" int stil_gemm_nt_variant(int M, int N) {
-  if (g_force_variant) return g_force_variant;
+// `tune` (per call, 0 = automatic; for A/B measurements): variant + 100 * bk32 + 1000 * acc2
+//   variant: block tile 22 = 128x128, 21 = 128x64, 11 = 64x64;  bk32: 1 = 32-deep LDS tiles (default 16);
+//   acc2: 1 = single-chain accumulation, 2 = two-level accumulation, 0 = two-level for K >= 512
+// which tile variant stil_gemm_nt launches for an [M,N] output
+extern "C" int stil_gemm_nt_variant(int M, int N, int tune) {
+  const int forced = tune % 100;
+  if (forced == 11 || forced == 21 || forced == 22) return forced;
   // measured (tests/tools/gemm_bench.py): fp32 MFMA is slow enough that 64x64 / 128x64 block tiles lose nothing to
   // 128x128 in operand reuse and win on occupancy + tile quantization over 256 CUs.
   if (N <= 64) return M <= 4096 ? 11 : 21;
@@ -545,15 +585,17 @@ extern "C" int stil_gemm_nt_variant(int M, int N) {
 }
 
 // rows per output tile of the variant stil_gemm_nt picks for [M,N] (the granularity of `colstats`)
-extern "C" int stil_gemm_nt_tile_rows(int M, int N) { return stil_gemm_nt_variant(M, N) == 11 ? 64 : 128; }
+extern "C" int stil_gemm_nt_tile_rows(int M, int N, int tune) { return stil_gemm_nt_variant(M, N, tune) == 11 ? 64 : 128; }
 
 extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                             int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad_y,
                             int pad_x, int mode, int out_stride, int out_py, int out_px, int out_OH, int out_OW,
                             const float* bias, const float* sub, const float* scale,
                             const float* shift, const float* resid, int ldr, float* pre, int act, float alpha,
-                            float* colstats, void* stream) {
+                            float* colstats, int tune, void* stream) {
   STIL_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0, "stil_gemm_nt: null pointer or empty shape (M=%d N=%d K=%d)", M, N, K);
+  STIL_REQUIRE(tune >= 0 && tune < 3000 && (tune % 100 == 0 || tune % 100 == 11 || tune % 100 == 21 || tune % 100 == 22) && (tune / 100) % 10 <= 1,
+               "stil_gemm_nt: bad tune %d", tune);
   STIL_REQUIRE(KH * KW * srcC == K, "stil_gemm_nt: K=%d != KH*KW*C=%d", K, KH * KW * srcC);
   STIL_REQUIRE(M % (OH * OW) == 0, "stil_gemm_nt: M=%d not a multiple of OH*OW=%d", M, OH * OW);
   GemmNTArgs p;
@@ -570,15 +612,20 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   int rc = check_geom(p.g, 0);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  const int variant = stil_gemm_nt_variant(M, N);
+  const int variant = stil_gemm_nt_variant(M, N, tune);
   // BK = 32 halves the barriers per MFMA and doubles the latency cover of the register prefetch; needs whole taps
-  const bool bk32 = g_gemm_bk == 32 && (K % 32 == 0) && (KH * KW == 1 || srcC % 32 == 0);
+  const bool bk32 = (tune / 100) % 10 == 1 && (K % 32 == 0) && (KH * KW == 1 || srcC % 32 == 0);
   rc = gemm_nt_attr();
   if (rc) return rc;
   const bool vec = p.vecA && p.vecB && (K % 4 == 0);  // every 16-byte load is aligned and entirely in or out
+  const bool acc2 = tune / 1000 == 2 || (tune / 1000 == 0 && K >= 512);   // long reductions: two-level accumulation (see gemm_nt_kernel)
 #define LAUNCH_NT(TM_, TN_, BK_, V_)                                                                          \
-  hipLaunchKernelGGL((gemm_nt_kernel<TM_, TN_, BK_, V_>), dim3(cdiv(M, 64 * TM_) * cdiv(N, 64 * TN_)), dim3(256), \
-                     (size_t)2 * 64 * (TM_ + TN_) * (BK_ + 4) * sizeof(float), s, p)
+  do {                                                                                                        \
+    const dim3 grid_(cdiv(M, 64 * TM_) * cdiv(N, 64 * TN_));                                                  \
+    const size_t lds_ = (size_t)2 * 64 * (TM_ + TN_) * (BK_ + 4) * sizeof(float);                             \
+    if (acc2) hipLaunchKernelGGL((gemm_nt_kernel<TM_, TN_, BK_, V_, true>), grid_, dim3(256), lds_, s, p);    \
+    else hipLaunchKernelGGL((gemm_nt_kernel<TM_, TN_, BK_, V_, false>), grid_, dim3(256), lds_, s, p);        \
+  } while (0)
   if (!vec) {  // unaligned / ragged operands (K = 286 classifier gradients ...): scalar guarded loads
     if (variant == 11) LAUNCH_NT(1, 1, 16, false); else if (variant == 21) LAUNCH_NT(2, 1, 16, false); else LAUNCH_NT(2, 2, 16, false);
   } else if (variant == 11) { if (bk32) LAUNCH_NT(1, 1, 32, true); else LAUNCH_NT(1, 1, 16, true); }
@@ -589,22 +636,16 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   return STIL_OK;
 }
 
-static int g_tn_variant = 0;   // 0 = automatic
-// tuning knob (A/B measurements only): block tile of the weight-gradient kernel, 22 = 128x128 (64x128 for N <= 64), 11 = 64x64
-extern "C" int stil_set_wgrad_variant(int v) {
-  if (v != 0 && v != 22 && v != 11) { stil_set_error("stil_set_wgrad_variant: bad variant %d", v); return STIL_EINVAL; }
-  g_tn_variant = v;
-  return STIL_OK;
-}
+// block tile of the weight-gradient kernel: 22 = 128x128 (64x128 for N <= 64), 11 = 64x64; `tune` forces one (0 = automatic).
 // measured in situ (bench.py --breakdown, cold caches): 64x64 tiles win for N <= 256 (more blocks, fewer M-splits) except the
 // 1x1 convolutions with 128..256 outputs and K in 256..1024, where 128x128 halves the operand re-reads
-static inline int tn_variant(int N, int K) {
-  if (g_tn_variant) return g_tn_variant;
+static inline int tn_variant(int N, int K, int tune) {
+  if (tune == 11 || tune == 22) return tune;
   if (N > 256) return 22;
   return (N >= 128 && K >= 256 && K <= 1024) ? 22 : 11;
 }
-static int wgrad_splits(int M, int N, int K) {
-  const int tv = tn_variant(N, K);
+static int wgrad_splits(int M, int N, int K, int tune) {
+  const int tv = tn_variant(N, K, tune);
   int tiles = tv == 11 ? cdiv(N, 64) * cdiv(K, 64) : cdiv(N, N <= 64 ? 64 : 128) * cdiv(K, 128);
   int want = cdiv(tv == 11 ? 2304 : 768, tiles);
   int maxs = M / 256 > 0 ? M / 256 : 1;
@@ -614,19 +655,20 @@ static int wgrad_splits(int M, int N, int K) {
   return s;
 }
 
-extern "C" size_t stil_wgrad_workspace_bytes(int M, int N, int K) {
-  return (size_t)wgrad_splits(M, N, K) * N * K * sizeof(float);
+extern "C" size_t stil_wgrad_workspace_bytes(int M, int N, int K, int tune) {
+  return (size_t)wgrad_splits(M, N, K, tune) * N * K * sizeof(float);
 }
 
 // dW (+)= dY^T . Xgather ; dW laid out [N, Kdst] (taps==1) or (N, Cin, KH, KW) (taps>1)
 extern "C" int stil_wgrad_tn(const float* dY, const float* X, float* dW, int M, int N, int K, int ldy, int ldx,
                              int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad,
-                             int Kdst, int accumulate, float* workspace, size_t workspace_bytes, void* stream) {
+                             int Kdst, int accumulate, float* workspace, size_t workspace_bytes, int tune, void* stream) {
   STIL_REQUIRE(dY && X && dW && workspace, "stil_wgrad_tn: null pointer");
+  STIL_REQUIRE(tune == 0 || tune == 11 || tune == 22, "stil_wgrad_tn: bad tune %d", tune);
   STIL_REQUIRE(KH * KW * srcC == K, "stil_wgrad_tn: K=%d != KH*KW*C=%d", K, KH * KW * srcC);
   STIL_REQUIRE(M % (OH * OW) == 0, "stil_wgrad_tn: M=%d not a multiple of OH*OW", M);
   STIL_REQUIRE(srcC % 4 == 0 || KH * KW == 1, "stil_wgrad_tn: conv needs Cin %% 4 == 0");
-  int splits = wgrad_splits(M, N, K);
+  int splits = wgrad_splits(M, N, K, tune);
   STIL_REQUIRE(workspace_bytes >= (size_t)splits * N * K * sizeof(float), "stil_wgrad_tn: workspace too small");
   GemmTNArgs p;
   p.Y = dY; p.X = X; p.P = workspace; p.M = M; p.N = N; p.K = K; p.ldy = ldy; p.ldx = ldx;
@@ -638,7 +680,7 @@ extern "C" int stil_wgrad_tn(const float* dY, const float* X, float* dW, int M, 
   p.vecX = is_vec(X, ldx) && (srcC % 4 == 0);
   hipStream_t s = (hipStream_t)stream;
   const bool vec = p.vecY && p.vecX && (N % 4 == 0) && (K % 4 == 0);
-  if (tn_variant(N, K) == 11) {
+  if (tn_variant(N, K, tune) == 11) {
     dim3 grid(cdiv(N, 64) * cdiv(K, 64) * splits);
     if (vec) hipLaunchKernelGGL((gemm_tn_kernel<1, 1, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((gemm_tn_kernel<1, 1, false>), grid, dim3(256), 0, s, p);

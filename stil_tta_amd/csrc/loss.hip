@@ -201,12 +201,31 @@ __global__ __launch_bounds__(256) void cgpl_pgls_kernel(CgplArgs p) {
   const float* zm = p.zm + (long)u * p.ldz;
   const float* zi = p.zi + (long)u * p.ldz;
   const float* zt = p.zt + (long)u * p.ldz;
-  // first-index argmax of each head (thread 0..2 scan: K is small, keeps ATen's tie rule)
-  if (tid < 3) {
-    const float* z = tid == 0 ? zm : (tid == 1 ? zi : zt);
-    float best = z[0]; int bi = 0;
-    for (int k = 1; k < K; ++k) if (z[k] > best) { best = z[k]; bi = k; }
-    ired[tid] = bi;
+  // top-1 of each head = argmax(softmax(z)), NOT argmax(z) (STiLModel.py:262-263): distinct logits whose probabilities
+  // round to the same fp32 value tie, and torch.argmax then returns the FIRST of the tied indices.  Wave w (0..2) owns
+  // head w: p_k = exp(z_k - max) / sum in fp32, per-lane running best (strictly greater -> earliest k of that lane),
+  // then a (value, index) reduction that prefers the smaller index among equal values.
+  if (tid < 192) {
+    const int h = tid >> 6, lane = tid & 63;
+    const float* z = h == 0 ? zm : (h == 1 ? zi : zt);
+    float mxz = -INFINITY;
+    for (int k = lane; k < K; k += 64) mxz = fmaxf(mxz, z[k]);
+    mxz = wave_max(mxz);
+    float se = 0.f;
+    for (int k = lane; k < K; k += 64) se += expf(z[k] - mxz);
+    se = wave_sum(se);
+    float best = -1.f; int bi = 0x7fffffff;
+    for (int k = lane; k < K; k += 64) {
+      const float pk = expf(z[k] - mxz) / se;
+      if (pk > best || pk != pk) { best = pk; bi = k; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) ired[h] = bi;
   }
   __syncthreads();
   const int a = ired[0], b = ired[1], d = ired[2];

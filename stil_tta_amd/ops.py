@@ -53,6 +53,10 @@ class _Workspace:
 
 _ws = _Workspace()
 
+# per-call tuning arguments of stil_gemm_nt / stil_wgrad_tn (include/stil_hip.h); 0 = automatic.  Only the measurement
+# tools and bench.py's A/B environment knobs (STIL_GEMM_TUNE, STIL_WGRAD_TUNE) set them.
+TUNE = {"gemm": int(__import__("os").environ.get("STIL_GEMM_TUNE", "0")), "wgrad": int(__import__("os").environ.get("STIL_WGRAD_TUNE", "0"))}
+
 
 class _SideStream:
     """Weight-gradient GEMMs leave the critical path of backward: they only feed the gradient slab, so they run on a
@@ -86,6 +90,12 @@ def side_stream(device):
     if not _side.enabled or torch.cuda.is_current_stream_capturing() or _prof_active():
         return None
     return _side.get(device)
+
+
+# Parity instrumentation: when set to {"relu": {}, "pool": {}}, every ReLU output of a gradient-carrying pass and
+# the max-pool winners are kept (by reference, no copy) under id(parameter) so that tests can replay the device's
+# piecewise-linear decisions in their float64 CPU checker (tests/test_gpu_step.py).  None in production.
+_trace = None
 
 
 def _grad_into(param: torch.Tensor, writer):
@@ -122,10 +132,10 @@ def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None,
         s2 = geom[7] * geom[7] if geom[9] == 1 else 1
         src = (M // (geom[3] * geom[4])) * geom[0] * geom[1] * geom[2]  # gather source (each element fetched once, ideally)
         nbytes = 4.0 * (src + N * K + M * N * (1 + (resid is not None) + (pre is not None)))
-        meta = (L.gemm_nt_variant(M, N), 2.0 * M * N * K / s2, (M, N, K, geom[5], geom[7], geom[9]), nbytes)
+        meta = (L.gemm_nt_variant(M, N, TUNE["gemm"]), 2.0 * M * N * K / s2, (M, N, K, geom[5], geom[7], geom[9]), nbytes)
     L.gemm_nt(_p(A), _p(W), _p(out), M, N, K, lda, ldb, ldc, *geom[:8], pads[0], pads[1], geom[9], *outmap,
               _p(bias), _p(sub), _p(scale), _p(shift), _p(resid),
-              (ldc if resid is not None else 0), _p(pre), act, float(alpha), _p(colstats), _stream(), meta=meta)
+              (ldc if resid is not None else 0), _p(pre), act, float(alpha), _p(colstats), TUNE["gemm"], _stream(), meta=meta)
     return out
 
 
@@ -135,11 +145,11 @@ def wgrad_tn(dY, X, dW, M, N, K, *, ldy=None, ldx=None, geom=None, Kdst=None, ac
     ldy = N if ldy is None else ldy
     ldx = geom[2] if ldx is None else ldx
     Kdst = K if Kdst is None else Kdst
-    nb = lib().wgrad_workspace_bytes(M, N, K)
+    nb = lib().wgrad_workspace_bytes(M, N, K, TUNE["wgrad"])
     w = _ws.get(nb, dY.device)
     L = lib()
     meta = (0, 2.0 * M * N * K, (M, N, K, geom[5], geom[7], 2)) if L._prof is not None else None
-    L.wgrad_tn(_p(dY), _p(X), _p(dW), M, N, K, ldy, ldx, *geom, Kdst, accumulate, _p(w), nb, _stream(), meta=meta)
+    L.wgrad_tn(_p(dY), _p(X), _p(dW), M, N, K, ldy, ldx, *geom, Kdst, accumulate, _p(w), nb, TUNE["wgrad"], _stream(), meta=meta)
 
 
 def wgrad_param(param, dY, X, M, N, K, **kw):
@@ -205,6 +215,8 @@ class LinearFn(torch.autograd.Function):
         y = gemm_nt(x2, weight, M, N, K, bias=bias, pre=pre, act=act)
         ctx.act = act
         ctx.has_bias = bias is not None
+        if _trace is not None and act == 1 and any(ctx.needs_input_grad):
+            _trace["relu"][id(weight)] = y.view(*x.shape[:-1], N)
         ctx.save_for_backward(x2, weight, bias, pre if act == 2 else (y if act == 1 else None))
         ctx.xshape = x.shape
         return y.reshape(*x.shape[:-1], N)
@@ -292,7 +304,7 @@ class ConvBnActFn(torch.autograd.Function):
             M = Nb * OH * OW
         ts = tile_rows = None
         if fused:  # the GEMM epilogue leaves per-tile (mean, M2) partials: no statistics pass over y
-            tile_rows = lib().gemm_nt_tile_rows(M, Cout)
+            tile_rows = lib().gemm_nt_tile_rows(M, Cout, TUNE["gemm"])
             ts = torch.empty((2 * ((M + tile_rows - 1) // tile_rows), Cout), dtype=torch.float32, device=dev)
         if stem is not None:
             y = gemm_nt(x, wpad, M, Cout, Kp, colstats=ts)
@@ -318,6 +330,8 @@ class ConvBnActFn(torch.autograd.Function):
             ws = _ws.get(nb, dev)
             lib().bn_train_fwd(_p(y), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(nbt), _p(resid), _p(z), _p(stats), M, Cout,
                                1 if relu else 0, 1e-5, 0.1, _p(ws), nb, _stream())
+        if _trace is not None and relu:
+            _trace["relu"][id(gamma)] = z.view(Nb, OH, OW, Cout)
         ctx.save_for_backward(x, w, gamma, beta, y, z, stats)
         ctx.cfg = (k, stride, pad, relu, stem is not None, resid is not None, geom, (Nb, OH, OW), stem)
         if passthrough:
@@ -465,6 +479,8 @@ class MaxPoolFn(torch.autograd.Function):
         y = torch.empty((Nb, OH, OW, C), dtype=torch.float32, device=x.device)
         idx = torch.empty((Nb, OH, OW, C), dtype=torch.uint8, device=x.device)
         lib().maxpool3x3s2_fwd(_p(x), _p(y), _p(idx), Nb, H, W_, C, OH, OW, _stream())
+        if _trace is not None and ctx.needs_input_grad[0]:
+            _trace["pool"]["maxpool"] = (idx, H, W_)
         ctx.save_for_backward(idx)
         ctx.shape = (Nb, H, W_, C, OH, OW)
         return y

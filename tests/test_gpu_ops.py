@@ -386,6 +386,39 @@ def test_cgpl_pgls_and_prototypes(ops):
         close(out[:, :Dp], ls / 2.0 + us, name="class_sum"); close(out[:, Dp:], lc / 2.0 + uc, name="class_count")
 
 
+def test_cgpl_top1_is_argmax_of_softmax_with_first_index_ties(ops):
+    """STiLModel.py:262-263 takes torch.argmax(torch.softmax(logits)): two DISTINCT logits whose probabilities round to
+    the same fp32 value tie and the first index wins, where argmax(logits) would pick the larger logit.  Crafted rows:
+    the maximum sits at column 5 and column 2 is one ulp below it (exp(-7.5e-9) == 1.0f), for each head in turn."""
+    import numpy as np
+    K, Dp = 9, 16
+    g = torch.Generator().manual_seed(3)
+    hi = np.float32(0.1)
+    lo = np.nextafter(hi, np.float32(0.0), dtype=np.float32)
+    assert lo < hi
+
+    def row(tie):
+        z = -1.0 - torch.rand(K, generator=g)
+        z[5] = float(hi)
+        z[2] = float(lo) if tie else -2.0
+        return z
+
+    # row u: which heads carry the near-tie (m, i, t)
+    pattern = [(0, 0, 0), (1, 1, 1), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1)]
+    zm = torch.stack([row(p_[0]) for p_ in pattern]); zi = torch.stack([row(p_[1]) for p_ in pattern]); zt = torch.stack([row(p_[2]) for p_ in pattern])
+    Bu = len(pattern)
+    a, b, d = zm.softmax(1).argmax(1), zi.softmax(1).argmax(1), zt.softmax(1).argmax(1)   # the reference's expression, ATen CPU
+    assert a.tolist() == [2 if p_[0] else 5 for p_ in pattern], "the crafted probabilities must tie on the CPU too"
+    assert zm.argmax(1).tolist() == [5] * Bu                                               # ... where argmax(logits) sees no tie
+    c1 = (a == b) & (a == d); c2i = (a == b) & (a != d); c2t = (a == d) & (a != b); c3 = ~(c1 | c2i | c2t)
+    feat = F.normalize(torch.randn(Bu, Dp, generator=g)); protos = F.normalize(torch.randn(K, Dp, generator=g))
+    mr = torch.zeros(Bu, dtype=torch.uint8)
+    _, _, _, flags, _, _ = ops.cgpl_pgls(dev(zm), dev(zi), dev(zt), dev(feat), dev(protos), dev(mr), 0.9, 0.1, 0.5, True)
+    cs = flags[:, 0].cpu()
+    want = (1 * c1 + 2 * c2i + 3 * c2t + 4 * c3).to(torch.uint8)
+    assert torch.equal(cs, want), (cs.tolist(), want.tolist())
+
+
 def test_ema_and_adam_slabs():
     from stil_tta_amd._lib import lib
     from stil_tta_amd.ops import _p, _stream
@@ -517,7 +550,7 @@ def test_bn_statistics_two_pass_and_tile_paths_agree_with_float64(ops, M, C, til
         rm, rv, nbt = dev(torch.zeros(C)), dev(torch.ones(C)), torch.zeros((), dtype=torch.long, device="cuda")
         stats = torch.empty(4, C, device="cuda"); z = torch.empty(M, C, device="cuda")
         if mode == "tiles":
-            T = L.gemm_nt_tile_rows(M, C)
+            T = L.gemm_nt_tile_rows(M, C, 0)
             ts = torch.empty(2 * ((M + T - 1) // T), C, device="cuda")
             y = ops.gemm_nt(Ad, Wd, M, C, K, colstats=ts)
             nb = L.bn_tiles_workspace_bytes(M, C, T)

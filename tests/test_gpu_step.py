@@ -11,7 +11,11 @@ import torch
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-TOL = 1e-4
+# north_star: 1e-4 fp32.  The bar here is tighter than that, set from the measured margin (worst scaled error over all
+# cases is printed by every test): |a - b| <= TOL * (1 + |b| + max|b|), which implies |dloss| <= 1e-4 * (1 + |loss|).
+TOL = 3e-5
+NORTH_STAR = 1e-4
+_worst = {}
 
 
 def _close(a, b, tol=TOL):
@@ -19,7 +23,95 @@ def _close(a, b, tol=TOL):
     b = np.asarray(b, dtype=np.float64)
     scale = np.abs(b).max() if b.size else 0.0
     err = np.abs(a - b)
+    if err.size:
+        _worst["scaled"] = max(_worst.get("scaled", 0.0), float((err / (1.0 + np.abs(b) + scale)).max()))
     return bool(np.all(err <= tol * (1.0 + np.abs(b) + scale))), float(err.max()) if err.size else 0.0
+
+
+def _scaled(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    if not b.size:
+        return 0.0
+    return float((np.abs(a - b) / (1.0 + np.abs(b) + np.abs(b).max())).max())
+
+
+def _fwd_check(bad, key, gpu, ref32, ref64, report):
+    """Forward parity of one quantity.  d = scaled error against the reference's (oracle's) CPU fp32 value.
+    Pass when d <= TOL (3e-5, tighter than the 1e-4 north star).  A quantity that two correct fp32 evaluations cannot
+    pin that tightly (the crafted, batch-centred teacher logits: large cancelling terms behind 50 eval-mode layers)
+    must instead (i) stay inside the north-star 1e-4 and (ii) be as close to the float64 oracle as the reference's own
+    fp32 value is: e_gpu <= 3 * e_ref + 1e-5."""
+    gpu = np.asarray(gpu, dtype=np.float64)
+    d = _scaled(gpu, ref32)
+    _worst["scaled"] = max(_worst.get("scaled", 0.0), d)
+    if d <= TOL:
+        return
+    e_ref, e_gpu = _scaled(ref32, ref64), _scaled(gpu, ref64)
+    report.append((key, f"d={d:.2e}", f"e_gpu64={e_gpu:.2e}", f"e_ref64={e_ref:.2e}"))
+    if not (d <= NORTH_STAR and e_gpu <= 3 * e_ref + 1e-5):
+        bad.append((key, d, e_gpu, e_ref))
+
+
+class _trace_decisions:
+    """Keep the device's ReLU outputs / max-pool winners of the student pass (ops._trace) for the duration of a step."""
+
+    def __enter__(self):
+        from stil_tta_amd import ops
+        ops._trace = {"relu": {}, "pool": {}}
+        return ops._trace
+
+    def __exit__(self, *a):
+        from stil_tta_amd import ops
+        ops._trace = None
+
+
+def _device_decisions(m, trace):
+    """ops._trace -> (relu, pool) in the oracle's tags and layouts (oracle/stil_oracle.py: force_decisions)."""
+    names = {id(p): n for n, p in m.named_parameters() if not n.startswith("ema.")}
+    relu = {}
+    for pid, z in trace["relu"].items():
+        tag = names[pid][: -len(".weight")]
+        if not tag.startswith("model."):
+            tag = "model.:" + tag                      # heads outside the backbone (projectors, CLUB estimators)
+        mask = z.detach() > 0
+        if z.ndim == 4:
+            mask = mask.permute(0, 3, 1, 2)            # NHWC -> NCHW
+        relu[tag] = mask.cpu().contiguous()
+    pool = {}
+    if "maxpool" in trace["pool"]:
+        idx, H, W = trace["pool"]["maxpool"]           # [N, OH, OW, C] uint8: tap = ky*3 + kx of the winner
+        t = idx.cpu().long()
+        N, OH, OW, C = t.shape
+        oy = torch.arange(OH).view(1, OH, 1, 1)
+        ox = torch.arange(OW).view(1, 1, OW, 1)
+        flat = (oy * 2 - 1 + t // 3) * W + (ox * 2 - 1 + t % 3)
+        pool["model.encoder_imaging.maxpool"] = flat.permute(0, 3, 1, 2).contiguous()
+    return relu, pool
+
+
+def _check_flips(flips):
+    """A unit may sit on the other side of its kink in float64 only if it is a genuine near-tie: its |pre-activation|
+    (for the max-pool: the gap between the two candidates) must be inside the north-star forward tolerance of that tensor
+    (an intermediate BatchNorm output over 16 x 2 x 2 samples is itself only good to ~2e-5 of its range in fp32)."""
+    for t, (n, mag, scale) in flips.items():
+        assert mag <= NORTH_STAR * (1.0 + scale), f"decision {t}: {n} units differ from float64 with |pre-activation| up to {mag:.2e} (tensor max {scale:.2e})"
+
+
+def _grad_errors(params, g64, e32_of):
+    """relative L2 error of every device gradient against the float64 oracle evaluated on the device's own
+    decisions, judged against the reference's own fp32-vs-fp64 distance e32: err <= 3 * e32 + 1e-4 for EVERY tensor."""
+    bad, ratios = [], []
+    for k, g in g64.items():
+        p = params[k]
+        if g is None:
+            assert not p._stil_touched, k
+            continue
+        e32 = e32_of(k)
+        err = float((p._gslot.cpu().double() - g).norm() / (g.norm() + 1e-30))
+        ratios.append(err / (3 * e32 + 1e-4))
+        if err > 3 * e32 + 1e-4:
+            bad.append(("grad " + k, err, e32))
+    return bad, ratios
 
 
 def _make_model(hp, sd):
@@ -54,8 +146,12 @@ def _check_flags(last, o, B_u):
     assert torch.equal(f[:, 1].bool(), o["mask1"])
 
 
-from oracle.make_golden import CASES, SCALARS, build_case  # noqa: E402
+from oracle.make_golden import CASES, SCALARS, build_case, run_oracle64  # noqa: E402
 from oracle import stil_oracle as O  # noqa: E402
+
+FWD_KEYS = ["y_hat_m", "y_hat_i", "y_hat_t", "x_si_enhance", "x_si", "x_ai", "x_st_enhance", "x_st", "x_at", "x_c", "feat_m", "feat_i",
+            "feat_t", "y_hat_m_e", "y_hat_i_e", "y_hat_t_e", "feat_m_e", "pseudo_label_orig", "pseudo_label", "prediction",
+            "class_sum", "class_count"]
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -67,57 +163,43 @@ def test_training_step_matches_reference_golden(name):
     m = _make_model(hp, sd)
     m.current_epoch = epoch
     opt = StilAdam(m.flat, lr=hp.lr_eval, weight_decay=hp.weight_decay_eval)
-    train_step(m, opt, _to_dev(batch), mask_random=mask_random, mi_masks=mi_masks)
-    torch.cuda.synchronize()
+    with _trace_decisions() as trace:
+        train_step(m, opt, _to_dev(batch), mask_random=mask_random, mi_masks=mi_masks)
+        torch.cuda.synchronize()
+        decisions = _device_decisions(m, trace)
     last = m.last
-    bad = []
-    for k in SCALARS:
-        ok, err = _close(last[k].detach().cpu().numpy(), fx["out_" + k])
-        if not ok:
-            bad.append((k, err))
-    for k in ["y_hat_m", "y_hat_i", "y_hat_t", "x_si_enhance", "x_si", "x_ai", "x_st_enhance", "x_st", "x_at", "x_c", "feat_m", "feat_i",
-              "feat_t", "y_hat_m_e", "y_hat_i_e", "y_hat_t_e", "feat_m_e", "pseudo_label_orig", "pseudo_label", "prediction",
-              "class_sum", "class_count"]:
-        ok, err = _close(last[k].detach().cpu().numpy(), fx["out_" + k])
-        if not ok:
-            bad.append((k, err))
+    bad, report = [], []
+    o64 = run_oracle64(hp, sd, batch, epoch, mask_random, mi_masks, decisions=decisions)   # float64, the device's decisions
+    for k in SCALARS + FWD_KEYS:
+        _fwd_check(bad, k, last[k].detach().cpu().numpy(), fx["out_" + k], o64[k].numpy(), report)
     f = last["flags"].cpu().numpy()
     for cid, key in ((1, "case1"), (2, "case2_i"), (3, "case2_t"), (4, "case3")):
         assert np.array_equal(f[:, 0] == cid, fx["out_" + key]), key
     assert np.array_equal(f[:, 1].astype(bool), fx["out_mask1"])
     params = _named_params(m)
-    # Gradients: deep train-mode-BN backward amplifies fp32 rounding, so the yardstick is the float64 truth.  The
-    # fixture stores gerr32 = relL2(reference fp32 grad, fp64 grad).  Two bounds:
-    #   (tight, on the MEDIAN tensor) err <= 3 * gerr32 + 1e-4: the HIP path is as close to fp64 as the reference's
-    #       own CPU fp32 path (1e-4 = north-star tolerance);
-    #   (loose, on EVERY tensor) err <= 3 * gerr32 + 1e-2: one ReLU / max-pool / threshold decision flipping
-    #       between two fp32 evaluations (a pre-activation within ~1e-4 of 0 among ~1e4 units) moves every gradient
-    #       upstream of it by ~1e-3..1e-2 relative (measured with tests/tools/grad_terms.py: all loss terms agree to
-    #       ~2e-5 except the one that crosses a flipped unit).  Per-operator parity is pinned at 5e-5 in test_gpu_ops.py.
-    ratios = []
+    # Gradients.  Yardstick: deep train-mode-BN backward amplifies fp32 rounding, so the fixture stores, per tensor,
+    # gerr32 = relL2(REFERENCE fp32 gradient, float64 gradient); the device must be as close to float64 as the
+    # reference's own CPU fp32 path is: err <= 3 * gerr32 + 1e-4 (1e-4 = north-star tolerance) for EVERY tensor.
+    # The float64 oracle is evaluated on the DEVICE's piecewise-linear decisions (ReLU signs, max-pool winners, exported
+    # through ops._trace): a pre-activation within rounding of 0 may land on the other side of the kink in another
+    # fp32 (or the fp64) evaluation, which moves every gradient upstream of it by O(1) of that unit's share although
+    # both runs are right; with the decisions pinned the comparison is between two evaluations of ONE smooth function.
+    flips = {t: v for t, v in o64["flips"].items() if v[0]}
+    _check_flips(flips)
+    gbad, ratios = _grad_errors(params, o64["grads"], lambda k: float(fx["gerr32_" + k]))
+    bad += gbad
     for key in fx.files:
-        if key.startswith("gnorm_"):
-            p = params[key[6:]]
-            n = float(p._gslot.double().norm()) if p._stil_touched else 0.0
-            if "g64norm_" + key[6:] not in fx.files:
-                assert n == 0.0, key  # grad None in the reference
-                continue
-            n64, e32 = float(fx["g64norm_" + key[6:]]), float(fx["gerr32_" + key[6:]])
-            ratios.append(abs(n - n64) / ((3 * e32 + 1e-4) * n64 + 1e-12))
-            if abs(n - n64) > (3 * e32 + 1e-2) * n64 + 1e-9:
-                bad.append((key, n, n64, e32))
-        elif key.startswith("grad64_"):
-            g64 = fx[key].astype(np.float64)
-            e32 = float(fx["gerr32_" + key[7:]])
-            err = np.linalg.norm(params[key[7:]]._gslot.cpu().double().numpy() - g64) / (np.linalg.norm(g64) + 1e-30)
-            ratios.append(err / (3 * e32 + 1e-4))
-            if err > 3 * e32 + 1e-2:
-                bad.append((key, err, e32))
+        if key.startswith("gnorm_") and "g64norm_" + key[6:] not in fx.files:
+            assert not params[key[6:]]._stil_touched, key  # grad None in the reference
         elif key.startswith("ssum_"):
             v = m.state_dict()[key[5:]].double()
             ref_abs = float(fx["sabs_" + key[5:]])
             if abs(float(v.sum()) - float(fx[key])) > 5e-5 * (1.0 + ref_abs):
                 bad.append((key, float(v.sum()), float(fx[key])))
+    print(f"[{name}] worst scaled forward error so far {_worst.get('scaled', 0.0):.2e}; beyond {TOL:g}: {report}")
+    print(f"[{name}] gradient error / (3*gerr32 + 1e-4): median {np.median(ratios):.3f}, p90 {np.percentile(ratios, 90):.3f}, "
+          f"max {np.max(ratios):.3f}; units deciding differently in float64: "
+          f"{ {t: v[0] for t, v in flips.items()} }")
     assert not bad, f"{len(bad)} mismatches, first: {bad[:10]}"
     # inference hooks (STiLModel.py:424-474, 517-533), eval-mode BatchNorm, on the REFERENCE's post-step weights:
     # the first Adam step moves every weight by ~+-lr whatever the size of its gradient (m/sqrt(v) ~ sign g), so
@@ -135,8 +217,6 @@ def test_training_step_matches_reference_golden(name):
                      ("test_probs", probs)):
         ok, err = _close(val.detach().cpu().numpy(), fx["out_" + key], 2e-4)
         assert ok, (key, err)
-    assert float(np.median(ratios)) <= 1.0, f"median gradient error / tight bound = {np.median(ratios):.3f}"
-    print(f"[{name}] gradient error / tight bound: median {np.median(ratios):.3f}, p90 {np.percentile(ratios, 90):.3f}, max {np.max(ratios):.3f}")
 
 
 def test_two_steps_match_oracle_dvm_native_shape():
@@ -144,7 +224,7 @@ def test_two_steps_match_oracle_dvm_native_shape():
     BN running stats + prototype commit, against the CPU oracle on identical seeded inputs."""
     from stil_tta_amd.driver import train_step
     from stil_tta_amd.flat import StilAdam
-    from oracle.make_golden import randomize_state, make_mi_masks, run_oracle64
+    from oracle.make_golden import randomize_state, make_mi_masks
     hp = O.default_hparams(batch_size=16, start_epoch=0, th1=0.02)
     sd = randomize_state(O.init_state(hp, seed=3), seed=4)
     g = torch.Generator().manual_seed(7)
@@ -159,32 +239,29 @@ def test_two_steps_match_oracle_dvm_native_shape():
         mm = {0: make_mi_masks(16, 16, 17, 512, 4, 0.1, seed=step)}
         sd_before = {k: v.clone() for k, v in sd.items()}
         o = O.full_step(sd, oopt, step, batch, hp, 1, mr, mm)
-        o64 = run_oracle64(hp, sd_before, batch, 1, mr, mm)  # float64 truth for the gradients
-        train_step(m, opt, _to_dev(batch), mask_random=mr, mi_masks=mm)
-        torch.cuda.synchronize()
-        bad = []
-        for k in SCALARS + ["y_hat_m", "y_hat_m_e", "feat_m", "feat_m_e", "pseudo_label", "prediction", "class_sum", "class_count"]:
-            ok, err = _close(m.last[k].detach().cpu().numpy(), o[k].numpy())
-            if not ok:
-                bad.append((step, k, err))
+        with _trace_decisions() as trace:
+            train_step(m, opt, _to_dev(batch), mask_random=mr, mi_masks=mm)
+            torch.cuda.synchronize()
+            decisions = _device_decisions(m, trace)
+        o64 = run_oracle64(hp, sd_before, batch, 1, mr, mm, decisions=decisions)  # float64 on the device's decisions
+        o64free = run_oracle64(hp, sd_before, batch, 1, mr, mm)                    # float64, own decisions: the yardstick
+        bad, report = [], []
+        for k in SCALARS + FWD_KEYS:
+            _fwd_check(bad, k, m.last[k].detach().cpu().numpy(), o[k].numpy(), o64[k].numpy(), report)
         _check_flags(m.last, o, 14)
         for nm, ref in (("threshold1_ratio", o["mask1"]), ("case1_ratio", o["case1"]), ("case2_i_ratio", o["case2_i"]),
                         ("case2_t_ratio", o["case2_t"]), ("case3_ratio", o["case3"])):   # logged like STiLModel.py:307-311
             assert abs(float(m.logged["multimodal.train." + nm]) - float(ref.float().mean())) < 1e-6, nm
         params = _named_params(m)
-        ratios = []
-        for k, gr in o["grads"].items():
-            if gr is None:
-                assert not params[k]._stil_touched, k
-                continue
-            g64 = o64["grads"][k]
-            e32 = float((gr.double() - g64).norm() / (g64.norm() + 1e-30))
-            eg = float((params[k]._gslot.cpu().double() - g64).norm() / (g64.norm() + 1e-30))
-            ratios.append(eg / (3 * e32 + 1e-4))
-            if eg > 3 * e32 + 1e-2:  # loose bound on every tensor, tight bound on the median (see the golden test)
-                bad.append((step, "grad " + k, eg, e32))
-        assert float(np.median(ratios)) <= 1.0, f"median gradient error / tight bound = {np.median(ratios):.3f}"
-        print(f"step {step}: gradient error / tight bound: median {np.median(ratios):.3f}, p90 {np.percentile(ratios, 90):.3f}, max {np.max(ratios):.3f}")
+
+        def e32_of(k):  # the CPU fp32 oracle's own distance from float64 (both on their own decisions)
+            g = o64free["grads"][k]
+            return float((o["grads"][k].double() - g).norm() / (g.norm() + 1e-30))
+
+        gbad, ratios = _grad_errors(params, o64["grads"], e32_of)   # every tensor: err <= 3 * e32 + 1e-4
+        bad += [(step,) + b for b in gbad]
+        print(f"step {step}: worst scaled forward error so far {_worst.get('scaled', 0.0):.2e}; beyond {TOL:g}: {report}")
+        print(f"step {step}: gradient error / (3*e32 + 1e-4): median {np.median(ratios):.3f}, p90 {np.percentile(ratios, 90):.3f}, max {np.max(ratios):.3f}")
         msd = m.state_dict()
         tr = set(O.trainable_keys(sd))
         for k, v in sd.items():
@@ -217,20 +294,103 @@ def test_two_steps_match_oracle_dvm_native_shape():
         m.training_epoch_end()
 
 
-def test_bench_shape_properties():
-    """BASELINE configs[1] shape (224 px, 64 columns, K = 286) at B = 32: size-independent properties."""
+def test_baseline_shape_step_matches_oracle():
+    """BASELINE.json configs[0] / [1] shape -- ResNet-50, 224 px, 16 categorical (cardinality 8) + 48 continuous columns,
+    K = 286, B = 32 (4 labelled + 28 unlabelled), epoch > start_epoch so every loss term is live, injected mask_random
+    and MI-layer dropout masks -- one full step (training_step + backward + Adam + EMA + prototype accumulation,
+    STiLModel.py:228-386) through the HIP path against oracle.full_step on the host cores: every forward quantity of
+    the golden test's key list, exact CGPL case ids / mask1, BN buffers + EMA teacher + prototype accumulators, and every
+    gradient tensor against the float64 oracle on the device's decisions."""
+    from stil_tta_amd.driver import train_step
+    from stil_tta_amd.flat import StilAdam
+    from oracle.make_golden import randomize_state, make_mi_masks, craft_heads
+    fl = [8] * 16 + [1] * 48
+    B, K = 32, 286
+    hp = O.default_hparams(img_size=224, field_lengths=fl, num_classes=K, batch_size=B, start_epoch=0, th1=0.5)
+    sd = randomize_state(O.init_state(hp, seed=21), seed=22)
+    g = torch.Generator().manual_seed(23)
+    sd["prototypes"] = torch.nn.functional.normalize(torch.randn(K, hp.projection_dim, generator=g))
+    batch = O.synthetic_batch(hp, B, seed=2022)
+    B_u = len(batch["u"][2])
+    mr = torch.rand(B_u, generator=g).ge(0.5)
+    mm = {0: make_mi_masks(B, 49, len(fl), 512, 4, hp.mi_drop, seed=5)}
+    # couple the three classifiers (imaging / tabular heads reuse the e_si / e_st slices of the multimodal head, whose
+    # e_st slice is boosted: token means over 64 columns vary little between samples) so that the CGPL cases are mixed
+    for pre_ in ("model.", "ema."):
+        sd[pre_ + "classifier_multimodal.weight"][:, 512:1024] *= 0.3
+        sd[pre_ + "classifier_multimodal.weight"][:, 1024:] *= 28.0
+    sd = craft_heads(sd, batch, hp, 1, mr, scale=6.0, fi=1.0, ft=1.0)
+    # th1 in the widest gap of the confidence ranking (prediction does not depend on th1): a mixed mask1 that no
+    # rounding difference can flip
+    with torch.no_grad():
+        pre = O.training_step({k: v.clone() for k, v in sd.items()}, batch, hp, 1, mr, None)
+    conf = pre["prediction"].max(1)[0].sort()[0]
+    lo = B_u // 4
+    gaps = conf[lo + 1: B_u - lo + 1] - conf[lo: B_u - lo]
+    j = int(gaps.argmax()) + lo
+    hp.th1 = float((conf[j] + conf[j + 1]) / 2)
+    assert float(gaps.max()) > 1e-4
+    sd0 = {k: v.clone() for k, v in sd.items()}
+
+    m = _make_model(hp, {k: v.clone() for k, v in sd0.items()})
+    m.current_epoch = 1
+    with _trace_decisions() as trace:
+        train_step(m, StilAdam(m.flat, lr=hp.lr_eval), _to_dev(batch), mask_random=mr, mi_masks=mm)
+        torch.cuda.synchronize()
+        decisions = _device_decisions(m, trace)
+    o = O.full_step(sd, {}, 1, batch, hp, 1, mr, mm)
+    assert 0 < int(o["mask1"].sum()) < B_u
+    assert sum(int(o[c].sum()) > 0 for c in ("case1", "case2_i", "case2_t", "case3")) >= 3, "CGPL cases must be mixed"
+    bad, report = [], []
+    o64 = run_oracle64(hp, sd0, batch, 1, mr, mm, decisions=decisions)
+    for k in SCALARS + FWD_KEYS:
+        _fwd_check(bad, k, m.last[k].detach().cpu().numpy(), o[k].numpy(), o64[k].numpy(), report)
+    _check_flags(m.last, o, B_u)
+    msd = m.state_dict()
+    tr = set(O.trainable_keys(sd))
+    for k, v in sd.items():
+        if k in tr:
+            if float((msd[k].cpu() - v).abs().max()) > 2.2 * hp.lr_eval:
+                bad.append(("adam " + k,))
+        else:  # BN running statistics, the EMA teacher, prototype accumulators
+            ok, err = _close(msd[k].cpu().double().numpy(), v.double().numpy(), 5e-5)
+            if not ok:
+                bad.append(("state " + k, err))
+    # gradients: float64 on the device's decisions; yardstick = the CPU fp32 oracle on the same decisions
+    with O.force_decisions(*decisions):
+        o32 = O.full_step({k: v.clone() for k, v in sd0.items()}, {}, 1, batch, hp, 1, mr, mm)
+    flips = {t: v for t, v in o64["flips"].items() if v[0]}
+    _check_flips(flips)
+
+    def e32_of(k):
+        g64 = o64["grads"][k]
+        return float((o32["grads"][k].double() - g64).norm() / (g64.norm() + 1e-30))
+
+    gbad, ratios = _grad_errors(_named_params(m), o64["grads"], e32_of)
+    bad += gbad
+    print(f"baseline shape: worst scaled forward error so far {_worst.get('scaled', 0.0):.2e}; beyond {TOL:g}: {report}")
+    print(f"baseline shape: gradient error / (3*e32 + 1e-4): median {np.median(ratios):.3f}, p90 {np.percentile(ratios, 90):.3f}, "
+          f"max {np.max(ratios):.3f}; th1 = {hp.th1:.4f}, mask1 {int(o['mask1'].sum())}/{B_u}, cases "
+          f"{[int(o[c].sum()) for c in ('case1', 'case2_i', 'case2_t', 'case3')]}; float64 decides differently on { {t: v[0] for t, v in flips.items()} }")
+    assert not bad, f"{len(bad)} mismatches, first: {bad[:10]}"
+
+
+@pytest.mark.parametrize("B", [32, 256])
+def test_bench_shape_properties(B):
+    """BASELINE configs[1] shape (224 px, 64 columns, K = 286) at B = 32 and at the bench's B = 256: size-independent
+    properties."""
     from stil_tta_amd import STiLModel
     from stil_tta_amd.driver import train_step, synthetic_batch
     from stil_tta_amd.flat import StilAdam
     torch.manual_seed(0)
     fl = [8] * 16 + [1] * 48
-    m = STiLModel(dict(field_lengths=fl, num_classes=286, start_epoch=0, batch_size=32, th1=0.0))
+    m = STiLModel(dict(field_lengths=fl, num_classes=286, start_epoch=0, batch_size=B, th1=0.0))
     m.setup_device("cuda")
     m.train()
     m.current_epoch = 1
     m.prototypes.copy_(torch.nn.functional.normalize(torch.randn(286, 128, device="cuda")))
     opt = StilAdam(m.flat, lr=1e-4)
-    batch = synthetic_batch(fl, 286, 32, 224, device="cuda")
+    batch = synthetic_batch(fl, 286, B, 224, device="cuda")
     ema0 = m.flat.ema.clone()
     p0 = m.flat.params.clone()
     loss = train_step(m, opt, batch)
@@ -242,9 +402,9 @@ def test_bench_shape_properties():
     for k in ("pseudo_label", "pseudo_label_orig", "prediction"):  # rows are distributions
         assert float((L[k].sum(1) - 1).abs().max()) < 1e-5, k
     f = L["flags"].cpu()
-    assert int(((f[:, 0] >= 1) & (f[:, 0] <= 4)).sum()) == 28  # the four cases partition the unlabelled rows
+    assert int(((f[:, 0] >= 1) & (f[:, 0] <= 4)).sum()) == B - B // 8  # the four cases partition the unlabelled rows
     # th1 = 0: every row is confident -> counts sum to the batch; class sums add up to the feature sum
-    assert abs(float(L["class_count"].sum()) - 32.0) < 1e-4
+    assert abs(float(L["class_count"].sum()) - float(B)) < 1e-4 * B
     assert float((L["class_sum"].sum(0) - L["feat_m_e"].sum(0)).abs().max()) < 1e-4
     # EMA: e' = m e + (1-m) p (student BEFORE Adam), exact
     n = m.flat.n_backbone_params
@@ -261,7 +421,7 @@ def test_bench_shape_properties():
     # determinism: an identical second model/step gives bit-identical loss and gradients
     g1 = m.flat.grads.clone()
     torch.manual_seed(0)
-    m2 = STiLModel(dict(field_lengths=fl, num_classes=286, start_epoch=0, batch_size=32, th1=0.0))
+    m2 = STiLModel(dict(field_lengths=fl, num_classes=286, start_epoch=0, batch_size=B, th1=0.0))
     m2.setup_device("cuda"); m2.train(); m2.current_epoch = 1
     m2.flat.params.copy_(p0); m2.flat.copy_student_to_teacher(); m2.flat.ema.copy_(ema0)
     m2.prototypes.copy_(m.prototypes)

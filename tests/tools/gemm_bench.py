@@ -34,7 +34,10 @@ def run_nt(shape):
     return ms, 2.0 * M * N * K / ms / 1e9
 
 NT += [(50176, 256, 1024, 1, 1, 0, 14), (12544, 512, 2048, 1, 1, 0, 7), (12544, 2048, 512, 1, 1, 0, 7), (50176, 1024, 256, 1, 1, 0, 14)]
-variants = [("v22", lambda: L.set_gemm_variant(22)), ("v21", lambda: L.set_gemm_variant(21)), ("v11", lambda: L.set_gemm_variant(11))]
+def tune(v):
+    return lambda: ops.TUNE.__setitem__("gemm", v)
+# tune = variant + 100 * bk32 + 1000 * acc2 (include/stil_hip.h): auto / single-chain accumulation / per tile variant
+variants = [("auto", tune(0)), ("auto-1chain", tune(1000)), ("v11", tune(11)), ("v11-1chain", tune(1011)), ("v21", tune(21)), ("v21-1chain", tune(1021)), ("v22", tune(22))]
 res = {}
 for r in range(2):  # interleaved rounds
     for name, setter in variants:
@@ -42,10 +45,10 @@ for r in range(2):  # interleaved rounds
         for sh in NT:
             ms, tf = run_nt(sh)
             res.setdefault((name, sh), []).append(tf)
-print(f"{'shape':46s} " + " ".join(f"{n:>10s}" for n, _ in variants))
+print(f"{'shape':46s} " + " ".join(f"{n:>11s}" for n, _ in variants))
 for sh in NT:
-    print(f"{str(sh):46s} " + " ".join(f"{max(res[(n, sh)]):10.1f}" for n, _ in variants))
-L.set_gemm_variant(0)
+    print(f"{str(sh):46s} " + " ".join(f"{max(res[(n, sh)]):11.1f}" for n, _ in variants))
+ops.TUNE["gemm"] = 0
 
 # ---- weight-gradient (TN) kernel: tile variants
 TN = [(50176, 256, 2304, 3, 14), (802816, 64, 576, 3, 56), (802816, 256, 64, 1, 56), (200704, 128, 1152, 3, 28), (50176, 1024, 256, 1, 14),
@@ -70,10 +73,10 @@ def run_tn(shape):
 res = {}
 for r in range(2):
     for v in (22, 11):
-        L.set_wgrad_variant(v)
+        ops.TUNE["wgrad"] = v
         for sh in TN:
             res.setdefault((v, sh), []).append(run_tn(sh)[1])
 print(f"{'wgrad shape':46s}       t22        t11")
 for sh in TN:
     print(f"{str(sh):46s} {max(res[(22, sh)]):10.1f} {max(res[(11, sh)]):10.1f}")
-L.set_wgrad_variant(0)
+ops.TUNE["wgrad"] = 0

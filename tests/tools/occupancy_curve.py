@@ -8,9 +8,9 @@ from stil_tta_amd._lib import lib
 
 L = lib()
 variant = int(sys.argv[1]) if len(sys.argv) > 1 else 11
-L.set_gemm_variant(variant)
+ops.TUNE["gemm"] = variant
 if len(sys.argv) > 2:
-    L.set_gemm_bk(int(sys.argv[2]))
+    ops.TUNE["gemm"] += 100 * (int(sys.argv[2]) == 32)
 BM = 64 if variant == 11 else 128
 BN = 128 if variant == 22 else 64
 for (N, K) in ((256, 2304), (256, 256), (1024, 512)):

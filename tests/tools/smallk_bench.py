@@ -9,7 +9,7 @@ for (M, N, K, res) in ((802816, 256, 64, False), (802816, 256, 64, True), (20070
     R = torch.randn(M, N, device="cuda") if res else None
     big = torch.empty(1 << 28, device="cuda")  # 1 GiB: flushes the caches between launches
     for v in (11, 21, 22):
-        L.set_gemm_variant(v)
+        ops.TUNE["gemm"] = v
         ts = []
         for _ in range(5):
             big.zero_()
@@ -19,4 +19,4 @@ for (M, N, K, res) in ((802816, 256, 64, False), (802816, 256, 64, True), (20070
         ms = min(ts)
         gb = 4.0 * (M * K + N * K + M * N * (2 if res else 1)) / 1e9
         print(f"({M},{N},{K}) resid={res} v{v}: {ms*1e3:7.1f} us  {2.0*M*N*K/ms/1e9:6.1f} TF  {gb/ms:5.2f} TB/s")
-L.set_gemm_variant(0)
+ops.TUNE["gemm"] = 0
