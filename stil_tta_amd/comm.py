@@ -1,0 +1,244 @@
+"""Data-parallel communication of the STiL step: one process per GPU, torch.distributed (backend "nccl" == RCCL
+over xGMI on ROCm; "gloo" in the CPU / shared-GPU tests).
+
+  * GradExchange      -- the gradient slab is all-reduced bucket by bucket WHILE backward is still running: a bucket
+                         (a contiguous range of the flat gradient slab, flat.py) goes out on a communication stream as
+                         soon as the last of its tensors has received its gradient; DDP's bucketed overlap, rebuilt on
+                         the slab (the reference trains under Lightning DDP, trainers/evaluate.py:170-179).
+  * sync_buffers      -- DDP broadcast_buffers semantics in ONE broadcast (student + teacher BN running statistics).
+  * broadcast_state   -- DDP's construction-time broadcast of parameters / buffers (+ Adam state, prototypes) from rank 0.
+  * AllGatherFn / allreduce_mean -- autograd-aware collectives for the optional `global_contrast` mode:
+                         ITC over the global batch, CLUB with global batch means.
+
+xGMI is point-to-point (7 links per GPU, per-link bound): buckets are few and large (32 MB), the one prototype
+exchange is a single [K, 129] message, and nothing else crosses the links.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+# ------------------------------------------------------------------------------------------ gradient exchange
+class GradExchange:
+    """Bucketed all-reduce of the flat gradient slab, overlapped with backward.
+
+    Buckets are contiguous slab ranges of ~`bucket_elems` floats cut at tensor boundaries.  How many "+=" each parameter
+    receives in one backward pass (shared weights receive several) is LEARNED: the first step under a given signature
+    (the model's set of live loss terms) runs with a plain post-backward exchange and records the per-tensor touch
+    counts and the order in which buckets completed; later steps launch each bucket as soon as its counts are met,
+    always in that recorded order (every rank issues the same sequence of collectives whatever its autograd engine
+    does).  A gradient arriving for a bucket that has already left is a bug and raises."""
+
+    def __init__(self, flat, bucket_elems: int = 8 << 20):
+        self.flat = flat
+        self.enabled = os.environ.get("STIL_OVERLAP_ALLREDUCE", "1") != "0"
+        offs = [(t._gslot.data_ptr() - flat._grads.data_ptr()) // 4 for t in flat.tensors]
+        ends = [o + (t.numel() + 1023) // 1024 * 1024 for o, t in zip(offs, flat.tensors)]
+        self.bucket_of: List[int] = []
+        self.ranges: List[Tuple[int, int]] = []
+        start = None
+        for i, (o, e) in enumerate(zip(offs, ends)):
+            gap = start is not None and o != ends[i - 1]   # the BN-buffer region between backbone and head parameters
+            if start is None or gap or e - start > bucket_elems:
+                if start is not None:
+                    self.ranges.append((start, ends[i - 1]))
+                start = o
+            self.bucket_of.append(len(self.ranges))
+        self.ranges.append((start, ends[-1]))
+        self.tid = {id(t): i for i, t in enumerate(flat.tensors)}
+        self.plans: Dict[object, Tuple[List[int], List[int]]] = {}   # signature -> (expected touches per tensor, bucket order)
+        self.comm_stream: Optional[torch.cuda.Stream] = None
+        self.active = False
+        self._reset(None)
+
+    def _reset(self, sig):
+        self.sig = sig
+        self.active = world_size() > 1
+        n = len(self.flat.tensors)
+        self.counts = [0] * n
+        self.last_touch = {}          # bucket -> sequence number of its latest contribution (learning step)
+        self.seq = 0
+        self.works = []
+        self.fired = set()
+        self.ready = set()
+        plan = self.plans.get(sig) if (sig is not None and self.enabled and self.active) else None
+        self.expect, self.fire_order = plan if plan else (None, None)
+        self.next_fire = 0
+        if self.expect is not None:
+            self.remaining = [0] * len(self.ranges)
+            for i, c in enumerate(self.expect):
+                self.remaining[self.bucket_of[i]] += c
+
+    # ---- called by the step driver
+    def begin(self, sig):
+        """Start of backward.  `sig` identifies the set of live loss terms (None: never overlap)."""
+        self._reset(sig)
+
+    def note(self, param):
+        """One gradient contribution to `param` has been ISSUED (on the current or the side stream)."""
+        if not self.active:
+            return
+        i = self.tid.get(id(param))
+        if i is None:
+            return
+        self.counts[i] += 1
+        b = self.bucket_of[i]
+        self.seq += 1
+        self.last_touch[b] = self.seq
+        if self.expect is None:            # learning step / no overlap: everything leaves in finish()
+            return
+        if b in self.fired:
+            raise RuntimeError(f"gradient for {self.flat.names[i]} arrived after its bucket was all-reduced "
+                               "(the backward graph changed under an unchanged signature)")
+        self.remaining[b] -= 1
+        if self.remaining[b] == 0:
+            self.ready.add(b)
+            while self.next_fire < len(self.fire_order) and self.fire_order[self.next_fire] in self.ready:
+                self._fire(self.fire_order[self.next_fire])
+                self.next_fire += 1
+
+    def _fire(self, b):
+        from . import ops
+        a, e = self.ranges[b]
+        slab = self.flat._grads[a:e]
+        if slab.is_cuda:
+            if self.comm_stream is None:
+                self.comm_stream = torch.cuda.Stream(slab.device)
+            cs = self.comm_stream
+            cs.wait_stream(torch.cuda.current_stream(slab.device))   # BN / LN / bias gradients (main stream)
+            for st in ops._side.streams.values():                    # weight gradients (side stream)
+                if st.device == slab.device:
+                    cs.wait_stream(st)
+            with torch.cuda.stream(cs):
+                self.works.append(dist.all_reduce(slab, op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            self.works.append(dist.all_reduce(slab, op=dist.ReduceOp.SUM, async_op=True))
+        self.fired.add(b)
+
+    def finish(self) -> float:
+        """After backward: send what has not left yet, wait for everything; returns the factor Adam scales by (1/world)."""
+        if not self.active:
+            return 1.0
+        self.flat.grads  # joins the side stream (weight gradients) into the current one
+        if self.expect is None:
+            # buckets that received gradients, ordered by their LAST contribution (the order they can leave in next time)
+            order = sorted(self.last_touch, key=self.last_touch.get)
+            if self.sig is not None and self.enabled:
+                self.plans[self.sig] = (list(self.counts), order)
+            pending = order
+        else:
+            if self.counts != self.expect:
+                raise RuntimeError("the set of parameters receiving gradients changed under an unchanged signature")
+            pending = self.fire_order[self.next_fire:]
+        for b in pending:
+            if b not in self.fired:
+                self._fire(b)
+        for wk in self.works:
+            wk.wait()
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        return 1.0 / world_size()
+
+
+def allreduce_flat(slab: torch.Tensor, bucket_elems: int = 64 << 20) -> float:
+    """SUM all-reduce of a flat fp32 slab in a few large buckets, after backward (no overlap).
+    Returns the factor the consumer must scale by (1/world) -- applied inside the Adam kernel."""
+    w = world_size()
+    if w == 1:
+        return 1.0
+    n = slab.numel()
+    works = [dist.all_reduce(slab[o:min(n, o + bucket_elems)], op=dist.ReduceOp.SUM, async_op=True) for o in range(0, n, bucket_elems)]
+    for wk in works:
+        wk.wait()
+    return 1.0 / w
+
+
+# ------------------------------------------------------------------------------------------ buffers / initial state
+def sync_buffers(model):
+    """DDP broadcast_buffers semantics: every rank starts the step with rank 0's BN running statistics, student AND EMA
+    teacher (the reference's LightningModule is wrapped whole, `ema` included).  The two buffer ranges live in
+    different slabs: they are packed into one staging buffer so that ONE broadcast crosses the links."""
+    if world_size() == 1:
+        return
+    model.setup_device()
+    slabs = model.flat.buffer_slabs()
+    if not slabs:
+        return
+    if len(slabs) == 1:
+        dist.broadcast(slabs[0], src=0)
+        return
+    stage = torch.cat([s.reshape(-1) for s in slabs])
+    dist.broadcast(stage, src=0)
+    if dist.get_rank() != 0:
+        o = 0
+        for s in slabs:
+            s.copy_(stage[o:o + s.numel()])
+            o += s.numel()
+
+
+def broadcast_state(model, optimizer=None):
+    """What DistributedDataParallel does at construction (and Lightning when it restores a checkpoint on every rank):
+    rank 0's parameters, buffers, EMA teacher, Adam moments / step counts and prototype buffers become everybody's,
+    so differently seeded or differently restored ranks cannot drift apart silently."""
+    if world_size() == 1:
+        return
+    model.setup_device()
+    f = model.flat
+    for t in (f.params, f.ema, f.exp_avg, f.exp_avg_sq, f.steps):
+        dist.broadcast(t, src=0)
+    for b in list(f.s_counters) + list(f.t_counters):
+        dist.broadcast(b, src=0)
+    for name, b in model.named_buffers():
+        if name.startswith(("prototypes", "DA_")) or name in ("queue", "queue_ptr"):
+            dist.broadcast(b, src=0)
+
+
+# ------------------------------------------------------------------------------------------ autograd-aware collectives
+class AllGatherFn(torch.autograd.Function):
+    """x [b, D] on every rank -> cat over ranks [world*b, D] (rank order).  Backward: the gathered tensor's gradient is
+    SUM-all-reduced and this rank's rows are returned.  Every rank evaluates the same global loss redundantly, so the
+    sum is world x the row gradient, which the 1/world of the gradient average (DDP semantics, folded into Adam) turns
+    back into d(global loss)/d(local rows)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        w, r = dist.get_world_size(), dist.get_rank()
+        x = x.contiguous()
+        out = torch.empty((w * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x) if hasattr(dist, "all_gather_into_tensor") and x.is_cuda and dist.get_backend() == "nccl" \
+            else out.copy_(torch.cat(_all_gather_list(x)))
+        ctx.rows = (r * x.shape[0], x.shape[0])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        o, n = ctx.rows
+        return g[o:o + n]
+
+
+def _all_gather_list(x):
+    parts = [torch.empty_like(x) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, x)
+    return parts
+
+
+def all_gather_rows(x: torch.Tensor) -> torch.Tensor:
+    return x if world_size() == 1 else AllGatherFn.apply(x)
+
+
+def allreduce_mean_(t: torch.Tensor) -> torch.Tensor:
+    """In-place mean over ranks of a statistics tensor (no autograd: used inside custom Functions)."""
+    if world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t.div_(dist.get_world_size())
+    return t

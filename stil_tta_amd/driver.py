@@ -40,43 +40,35 @@ def init_distributed(backend: Optional[str] = None):
     return rank, world, local
 
 
-def world_size() -> int:
-    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+from .comm import GradExchange, allreduce_flat, broadcast_state, sync_buffers, world_size  # noqa: E402,F401  (re-exported)
 
 
-def allreduce_flat(slab: torch.Tensor, bucket_elems: int = 64 << 20):
-    """SUM all-reduce of a flat fp32 slab in a few large buckets (xGMI is per-link bound: big messages).
-    Returns the factor the consumer must scale by (1/world) -- applied inside the Adam kernel."""
-    w = world_size()
-    if w == 1:
-        return 1.0
-    n = slab.numel()
-    works = []
-    for o in range(0, n, bucket_elems):
-        works.append(dist.all_reduce(slab[o:min(n, o + bucket_elems)], op=dist.ReduceOp.SUM, async_op=True))
-    for wk in works:
-        wk.wait()
-    return 1.0 / w
-
-
-def sync_buffers(model):
-    """DDP broadcast_buffers semantics: every rank starts the step with rank 0's BN running statistics (student and
-    EMA teacher); two contiguous broadcasts of the buffer ranges of the flat slabs."""
-    if world_size() == 1:
-        return
-    model.setup_device()
-    for slab in model.flat.buffer_slabs():
-        dist.broadcast(slab, src=0)
+def _exchange_of(model):
+    """The model's gradient exchange (created on first use, registered with the operator layer)."""
+    from . import ops
+    ex = getattr(model, "_grad_exchange", None)
+    if ex is None or ex.flat is not model.flat:
+        ex = model._grad_exchange = GradExchange(model.flat)
+    ops._exchange = ex if world_size() > 1 else None
+    return ex
 
 
 def train_step(model, optimizer, batch, mask_random=None, mi_masks=None):
-    """One optimisation step. Returns the (detached) loss tensor; no host sync."""
+    """One optimisation step. Returns the (detached) loss tensor; no host sync.
+    Data parallel (world > 1): rank 0's state is broadcast once before the first step (DDP's constructor), BN running
+    statistics before every step (DDP broadcast_buffers, one message), and the gradient slab is all-reduced in buckets
+    while backward is still running (comm.GradExchange); the 1/world of the gradient average is folded into Adam."""
+    if world_size() > 1 and not getattr(model, "_state_broadcast", False):
+        broadcast_state(model, optimizer)
+        model._state_broadcast = True
     sync_buffers(model)
     optimizer.zero_grad()
     kw = {k: v for k, v in (('mask_random', mask_random), ('mi_masks', mi_masks)) if v is not None}  # STiL's injected randomness
     loss = model.training_step(batch, 0, **kw)
+    ex = _exchange_of(model)
+    ex.begin(getattr(model, "grad_signature", lambda: None)())
     loss.backward()
-    optimizer.grad_scale = allreduce_flat(model.flat.grads)
+    optimizer.grad_scale = ex.finish()
     optimizer.step()
     return loss.detach()
 

@@ -4,9 +4,11 @@
   * train loader dict {'l', 'u'} combined in `max_size_cycle` mode (Lightning's default for a dict of loaders in fit:
     an epoch lasts as long as the longest loader, shorter ones restart) -- trainers/evaluate.py:116-119;
   * `split_batch_size` / `repeat_ratio` of trainers/evaluate.py:82-85;
-  * per epoch: train steps -> training_epoch_end -> (every check_val_every_n_epoch) validation ->
-    validation_epoch_end -> ModelCheckpoint(monitor eval.val.<metric>, mode max, checkpoint_best_<metric>.ckpt)
-    -> EarlyStopping(min_delta 1e-4, patience int(scale / val_check_interval)) -> LR scheduler step
+  * per epoch: train steps -> training_epoch_end -> epoch-interval LR scheduler step (Lightning 1.6 steps it in
+    TrainingEpochLoop.on_advance_end, BEFORE validation and checkpointing, so a checkpoint carries the learning rate of
+    the NEXT epoch) -> (every check_val_every_n_epoch) validation -> validation_epoch_end ->
+    ModelCheckpoint(monitor eval.val.<metric>, mode max, checkpoint_best_<metric>.ckpt) -> EarlyStopping(min_delta
+    1e-4, patience int(scale / val_check_interval)) -> ReduceLROnPlateau step, which needs the validation metric
     (trainers/evaluate.py:170-179);
   * checkpoints are Lightning-shaped dicts (`state_dict` with the reference's key names, `hyper_parameters`,
     `optimizer_states` in torch.optim.Adam layout over the reference's six parameter groups, `lr_schedulers`, `epoch`,
@@ -214,9 +216,12 @@ def fit(model, train_loaders: Dict[str, Iterable], val_loader: Optional[Iterable
         stopper.best, stopper.wait = float(ck.get("stopper_best", -math.inf)), int(ck.get("stopper_wait", 0))
     stopped = "max_epochs"
     last_val: Dict[str, float] = {}
+    lrs: Dict[int, float] = {}
+    plateau = isinstance(sched, torch.optim.lr_scheduler.ReduceLROnPlateau)  # scheduler: linear (monitors the validation metric)
     for epoch in range(start_epoch, max_epochs):
         model.train()
         model.current_epoch = epoch
+        lrs[epoch] = float(opt.param_groups[0]["lr"])
         stream = max_size_cycle(train_loaders)
         if prefetch:  # host batches: pinned staging + H2D copies on a copy stream, two batches ahead (data.DevicePrefetcher)
             from .data import DevicePrefetcher
@@ -227,6 +232,8 @@ def fit(model, train_loaders: Dict[str, Iterable], val_loader: Optional[Iterable
             train_step(model, opt, _to_device(batch, dev))
             gstep += 1
         model.training_epoch_end()
+        if sched is not None and not plateau:
+            sched.step()
         if val_loader is not None and (epoch + 1) % check_val_every_n_epoch == 0:
             last_val = validate(model, val_loader, limit_val_batches)
             score = last_val[ckpt.monitor]
@@ -239,16 +246,12 @@ def fit(model, train_loaders: Dict[str, Iterable], val_loader: Optional[Iterable
             if stopper.should_stop(score):
                 stopped = "early_stopping"
                 break
-        if sched is not None:
-            if isinstance(sched, torch.optim.lr_scheduler.ReduceLROnPlateau):  # scheduler: linear (monitors the validation metric)
-                if last_val:
-                    sched.step(last_val[ckpt.monitor])
-            else:
-                sched.step()
+        if plateau and last_val:
+            sched.step(last_val[ckpt.monitor])
     if world_size() > 1:
         dist.barrier()
     return dict(best_score=ckpt.best, best_epoch=ckpt.best_epoch, checkpoint=ckpt.path, epochs_run=epoch + 1 - start_epoch if max_epochs > start_epoch else 0,
-                global_step=gstep, stopped=stopped, callback_metrics=last_val, best_val_score=model.best_val_score)
+                global_step=gstep, stopped=stopped, callback_metrics=last_val, best_val_score=model.best_val_score, lr_by_epoch=lrs)
 
 
 def test(model, test_loader, ckpt_path: Optional[str] = None, limit_batches: Optional[int] = None) -> Dict[str, float]:

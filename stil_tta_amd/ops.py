@@ -68,6 +68,19 @@ class _SideStream:
         import os
         self.enabled = os.environ.get("STIL_WGRAD_STREAM", "1") != "0"
         self.streams = {}
+        # (event recorded on the side stream after a launch, the tensors that launch reads).  Holding the references
+        # (1) keeps the autograd engine from accumulating IN PLACE into a gradient buffer a pending side-stream kernel
+        # still has to read (the engine only does that when it holds the last reference), and (2) keeps the allocator
+        # from handing the block to a main-stream allocation before the side stream is done with it.
+        self.keep = []
+
+    def retire(self, everything=False):
+        """Drop the references whose side-stream work has completed (or all of them, after a join)."""
+        k = self.keep
+        i = 0
+        while i < len(k) and (everything or k[i][0].query()):
+            i += 1
+        del k[:i]
 
     def get(self, device):
         st = self.streams.get(device)
@@ -83,6 +96,7 @@ def join_side():
     """Make the current stream wait for every side-stream launch issued so far."""
     for st in _side.streams.values():
         torch.cuda.current_stream(st.device).wait_stream(st)
+    _side.retire(everything=True)   # the current stream is now ordered after every side-stream read
 
 
 def side_stream(device):
@@ -98,13 +112,25 @@ def side_stream(device):
 _trace = None
 
 
+# data-parallel runs: the comm.GradExchange that is told about every gradient contribution as it is issued, so that
+# finished buckets of the gradient slab can be all-reduced while backward is still running (None: single process)
+_exchange = None
+
+
+def _touch(param):
+    """`param`'s gradient slot has just received a contribution (the launch is already enqueued)."""
+    param._stil_touched = True
+    if _exchange is not None:
+        _exchange.note(param)
+
+
 def _grad_into(param: torch.Tensor, writer):
     """Run writer(dst, accumulate) for a parameter gradient.  Slab-backed parameters get "+=" into their slot
     (returns None for autograd); plain tensors get a fresh gradient tensor (returned)."""
     slot = getattr(param, "_gslot", None)
     if slot is not None:
         writer(slot, 1)
-        param._stil_touched = True
+        _touch(param)
         return None
     g = torch.empty_like(param)
     writer(g, 0)
@@ -160,13 +186,16 @@ def wgrad_param(param, dY, X, M, N, K, **kw):
     if side is None:
         return _grad_into(param, lambda dst, acc: wgrad_tn(dY, X, dst, M, N, K, accumulate=acc, **kw))
     main = torch.cuda.current_stream()
+    _side.retire()
     if main != side:
         side.wait_stream(main)
-        dY.record_stream(side)
-        X.record_stream(side)
     with torch.cuda.stream(side):
         wgrad_tn(dY, X, slot, M, N, K, accumulate=1, **kw)
-    param._stil_touched = True
+        if main != side:
+            ev = torch.cuda.Event()
+            ev.record(side)
+            _side.keep.append((ev, (dY, X)))
+    _touch(param)
     return None
 
 
@@ -358,8 +387,8 @@ class ConvBnActFn(torch.autograd.Function):
         lib().bn_train_bwd(_p(gz), _p(z), _p(y), _p(gamma), _p(stats), _p(dy), _p(gres), _p(dgamma), _p(dbeta), _p(coef), M,
                            Cout, (1 if has_res else 2) if relu else 0, acc, _p(ws), nb, _stream())
         if gslot is not None:
-            gamma._stil_touched = True
-            beta._stil_touched = True
+            _touch(gamma)
+            _touch(beta)
         if has_res:
             dres = gres if relu else gz.view(M, Cout)
         else:
@@ -523,8 +552,8 @@ class LayerNormFn(torch.autograd.Function):
         lib().layernorm_bwd(_p(gy), _p(x), _p(gamma), _p(mr), _p(dx), _p(dg), _p(db), rows, D, 1 if gslot is not None else 0,
                             _p(ws), nb, _stream())
         if gslot is not None:
-            gamma._stil_touched = True
-            beta._stil_touched = True
+            _touch(gamma)
+            _touch(beta)
             return dx, None, None
         return dx, dg, db
 
@@ -641,7 +670,7 @@ class TabEmbedFn(torch.autograd.Function):
         if use_slab:
             for p_ in params:
                 if p_ is not None:
-                    p_._stil_touched = True
+                    _touch(p_)
             return (None,) * 9
         return (None, outs[0], outs[1], outs[2], outs[3], outs[4], None, None, None)
 
@@ -767,9 +796,15 @@ class ClipFromLogitsFn(torch.autograd.Function):
         return dZ, None
 
 
-def clip_loss(f0, f1, T, lam0):
-    """CLIPLoss.forward (utils/clip_loss.py:27-39). Returns (loss, logits)."""
+def clip_loss(f0, f1, T, lam0, gather=False):
+    """CLIPLoss.forward (utils/clip_loss.py:27-39). Returns (loss, logits).
+    gather (data-parallel `global_contrast`): both embeddings are all-gathered with autograd
+    (comm.AllGatherFn) and every rank evaluates the loss over the GLOBAL batch, like MMatch.py:411-418 does for its
+    memory bank; off by default because the reference's STiL keeps its ITC negatives rank-local."""
     n0, n1 = l2norm(f0), l2norm(f1)
+    if gather:
+        from .comm import all_gather_rows
+        n0, n1 = all_gather_rows(n0), all_gather_rows(n1)
     Z = MatmulNTFn.apply(n0, n1, 1.0 / T)
     return ClipFromLogitsFn.apply(Z, float(lam0)), Z
 
@@ -778,7 +813,10 @@ class ClubFn(torch.autograd.Function):
     """CLUBMean.forward + learning_loss given mu = p_mu(x)  (club.py:107-130), closed form over the batch."""
 
     @staticmethod
-    def forward(ctx, mu, y):
+    def forward(ctx, mu, y, global_stats=False):
+        """global_stats (data-parallel `global_contrast`): the batch means of y and mu are averaged over the ranks, which
+        makes the rank-mean of this loss (and of its gradients, after the data-parallel 1/world) equal to the closed
+        form over the global batch: two [D] all-reduces instead of moving samples."""
         _chk(mu, y)
         R, D = y.shape
         dev = y.device
@@ -786,6 +824,10 @@ class ClubFn(torch.autograd.Function):
         mubar = torch.empty((D,), dtype=torch.float32, device=dev)
         colsum(y, ybar, R, D, scale=1.0 / R)
         colsum(mu, mubar, R, D, scale=1.0 / R)
+        if global_stats:
+            from .comm import allreduce_mean_
+            allreduce_mean_(ybar)
+            allreduce_mean_(mubar)
         tmp = torch.empty((2, R), dtype=torch.float32, device=dev)
         out2 = torch.empty((2,), dtype=torch.float32, device=dev)
         lib().club_fwd(_p(mu), _p(y), _p(ybar), _p(tmp), _p(out2), R, D, _stream())
@@ -800,7 +842,7 @@ class ClubFn(torch.autograd.Function):
         dy = torch.empty_like(y)
         lib().club_bwd(_p(mu), _p(y), _p(ybar), _p(mubar), _p(gc.contiguous()), _p(ge.contiguous()), _p(dmu), _p(dy), R, D,
                        _stream())
-        return dmu, dy
+        return dmu, dy, None
 
 
 class ProtoLossFn(torch.autograd.Function):
@@ -901,7 +943,7 @@ class SaintEmbedColMlpFn(torch.autograd.Function):
                              d, acc, _stream())
         if use_slab:
             for p_ in params:
-                p_._stil_touched = True
+                _touch(p_)
             return (None,) * (4 + len(mlp_params))
         return (None, outs[0], outs[1], None, *outs[2:])
 

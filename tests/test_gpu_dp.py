@@ -17,11 +17,11 @@ FL = [3, 4] + [1] * 3
 HP = dict(model="resnet18", embedding_dim=512, field_lengths=FL, num_classes=5, start_epoch=0, batch_size=16, th1=0.3, mi_dropout=False)
 
 
-def _make():
+def _make(seed=0, **over):
     from stil_tta_amd import STiLModel
     from stil_tta_amd.flat import StilAdam
-    torch.manual_seed(0)
-    m = STiLModel(dict(HP))
+    torch.manual_seed(seed)
+    m = STiLModel(dict(HP, **over))
     m.setup_device("cuda"); m.train(); m.current_epoch = 1
     m.prototypes.copy_(torch.nn.functional.normalize(torch.randn(5, 128, generator=torch.Generator().manual_seed(1))).cuda())
     return m, StilAdam(m.flat, lr=1e-3)
@@ -34,53 +34,139 @@ def _worker(rank, world, port, outdir):
     import torch.distributed as dist
     from stil_tta_amd.driver import init_distributed, shard_batch, synthetic_batch, sync_buffers, train_step
     init_distributed()
-    m, opt = _make()
+    m, opt = _make(seed=rank)   # differently seeded ranks: the first step broadcasts rank 0's state (DDP's constructor)
     batch = shard_batch(synthetic_batch(FL, 5, 32, 64, seed=3, device="cuda"), rank, world)
-    mr = (torch.arange(7) % 2 == rank).cuda()
+    mr = (torch.arange(14) % 2 == rank).cuda()
+    own0 = m.flat.params.cpu()
     train_step(m, opt, batch, mask_random=mr)
     torch.cuda.synchronize()
-    out = dict(grads=m.flat.grads.cpu(), params=m.flat.params.cpu(), psum=m.prototypes_sum.cpu(), pcnt=m.prototypes_count_sum.cpu(),
+    out = dict(own0=own0, grads=m.flat.grads.cpu(), params=m.flat.params.cpu(), psum=m.prototypes_sum.cpu(), pcnt=m.prototypes_count_sum.cpu(),
                buf=(m.flat.n_backbone_params, m.flat.n_backbone_state))
     sync_buffers(m)  # what the next step starts with: rank 0's BN running statistics (DDP broadcast_buffers)
     torch.cuda.synchronize()
     out.update(params_synced=m.flat.params.cpu(), ema_synced=m.flat.ema.cpu())
+    # two more steps: from the second step on the gradient buckets leave while backward is still running
+    ex = m._grad_exchange
+    for s_ in (4, 5):
+        b2 = shard_batch(synthetic_batch(FL, 5, 32, 64, seed=s_, device="cuda"), rank, world)
+        train_step(m, opt, b2, mask_random=mr)
+    torch.cuda.synchronize()
+    out.update(params3=m.flat.params.cpu(), overlapped=bool(ex.expect is not None), plans=len(ex.plans), nbuckets=len(ex.ranges))
+    # global_contrast at the operator level: ITC over the all-gathered batch, CLUB with global batch means
+    from stil_tta_amd import ops
+    g = torch.Generator().manual_seed(11)
+    fi, ft = torch.randn(16, 128, generator=g), torch.randn(16, 128, generator=g)
+    mu, yy = torch.randn(16, 64, generator=g), torch.randn(16, 64, generator=g) + 0.5
+    sl = slice(rank * 8, rank * 8 + 8)
+    fid, ftd = fi[sl].cuda().requires_grad_(), ft[sl].cuda().requires_grad_()
+    loss_itc, _ = ops.clip_loss(fid, ftd, 0.1, 0.5, gather=True)
+    loss_itc.backward()
+    mud, yd = mu[sl].cuda().requires_grad_(), yy[sl].cuda().requires_grad_()
+    c, e = ops.ClubFn.apply(mud, yd, True)
+    (1.5 * c + 0.5 * e).backward()
+    torch.cuda.synchronize()
+    out.update(itc=loss_itc.detach().cpu(), dfi=fid.grad.cpu(), dft=ftd.grad.cpu(), club=c.detach().cpu(), est=e.detach().cpu(),
+               dmu=mud.grad.cpu(), dy=yd.grad.cpu())
     torch.save(out, os.path.join(outdir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
+def _run_pair(target, td, env=None):
+    """Two ranks sharing the GPU; a rank that hangs is terminated and reported (its log is the evidence, not a re-run)."""
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        ps = [ctx.Process(target=target, args=(r, 2, port, td)) for r in range(2)]
+        for p in ps:
+            p.start()
+        hung = False
+        for p in ps:
+            p.join(timeout=300)
+            if p.is_alive():
+                hung = True
+                p.terminate(); p.join(timeout=10)
+                if p.is_alive():
+                    p.kill(); p.join()
+        assert not hung, "a data-parallel worker hung and was killed: investigate from its output"
+        assert [p.exitcode for p in ps] == [0, 0], [p.exitcode for p in ps]
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    return torch.load(os.path.join(td, "rank0.pt")), torch.load(os.path.join(td, "rank1.pt"))
+
+
 def test_two_rank_step_equals_sum_of_shards():
     from stil_tta_amd.driver import shard_batch, synthetic_batch
     with tempfile.TemporaryDirectory() as td:
-        ctx = mp.get_context("spawn")
-        port = 29800 + os.getpid() % 100
-        ps = [ctx.Process(target=_worker, args=(r, 2, port, td)) for r in range(2)]
-        for p in ps:
-            p.start()
-        for p in ps:
-            p.join(timeout=300)
-            assert p.exitcode == 0
-        r0, r1 = torch.load(os.path.join(td, "rank0.pt")), torch.load(os.path.join(td, "rank1.pt"))
-    a, b = r0["buf"]
-    assert torch.equal(r0["params"][:a], r1["params"][:a]) and torch.equal(r0["params"][b:], r1["params"][b:]), "ranks diverged"
-    assert not torch.equal(r0["params"][a:b], r1["params"][a:b])  # BN running stats are per-shard until the next sync
-    assert torch.equal(r0["params_synced"], r1["params_synced"]) and torch.equal(r0["ema_synced"], r1["ema_synced"])
-    assert torch.equal(r0["params_synced"], r0["params"])  # rank 0 is the source
-    assert torch.equal(r0["grads"], r1["grads"]) and torch.equal(r0["psum"], r1["psum"])
+        r0, r1 = _run_pair(_worker, td)
+    with tempfile.TemporaryDirectory() as td:   # the same three steps with the plain post-backward exchange
+        p0, p1 = _run_pair(_worker, td, env={"STIL_OVERLAP_ALLREDUCE": "0"})
+    assert r0["overlapped"] and r0["plans"] == 1 and r0["nbuckets"] >= 2 and not p0["overlapped"]
+    a_, b_ = r0["buf"]
     # single-process reference: each shard alone (no process group), gradients / class sums added by hand
     full = synthetic_batch(FL, 5, 32, 64, seed=3, device="cuda")
     gsum, psum, pcnt = None, None, None
     for rank in range(2):
         m, opt = _make()
         m.flat.zero_grad()
-        loss = m.training_step(shard_batch(full, rank, 2), 0, mask_random=(torch.arange(7) % 2 == rank).cuda())
+        loss = m.training_step(shard_batch(full, rank, 2), 0, mask_random=(torch.arange(14) % 2 == rank).cuda())
         loss.backward()
         torch.cuda.synchronize()
         g = m.flat.grads.cpu()
         gsum = g if gsum is None else gsum + g
         psum = m.prototypes_sum.cpu() if psum is None else psum + m.prototypes_sum.cpu()
         pcnt = m.prototypes_count_sum.cpu() if pcnt is None else pcnt + m.prototypes_count_sum.cpu()
+    errs = []
+    for nm, t in zip(m.flat.names, m.flat.tensors):
+        o = (t._gslot.data_ptr() - m.flat._grads.data_ptr()) // 4
+        n = t.numel()
+        errs.append((float((r0["grads"][o:o + n] - gsum[o:o + n]).abs().max()), nm, o, n))
+    print("WORST", sorted(errs, reverse=True)[:8], "n_bad", sum(1 for e in errs if e[0] > 1e-5), "of", len(errs))
     scale = float(gsum.abs().max())
+    print("GRADS vs single-process shard sum: overlap-run", float((r0["grads"] - gsum).abs().max()), "plain-run", float((p0["grads"] - gsum).abs().max()), "scale", scale)
+
+    def same(x, y):
+        return torch.equal(x[:a_], y[:a_]) and torch.equal(x[b_:], y[b_:])
+
+    print("DIAG", {k: (float((r0[k] - p0[k]).abs().max()), float((r1[k] - p1[k]).abs().max())) for k in ("own0", "grads", "params", "psum", "params3")},
+          float((r0["own0"] - r1["own0"]).abs().max()))
+    diag = dict(step1_run_to_run=same(r0["params"], p0["params"]), step3_ranks_overlap=same(r0["params3"], r1["params3"]),
+                step3_ranks_plain=same(p0["params3"], p1["params3"]), step3_overlap_vs_plain=same(r0["params3"], p0["params3"]))
+    assert all(diag.values()), diag   # ranks agree; overlapping the exchange changes no bit
+    # global_contrast: two ranks == one process at batch 16 (ITC: every rank evaluates the global loss; CLUB: the rank
+    # mean is the global closed form; gradients: rank gradient / world == the single-process gradient rows)
+    from stil_tta_amd import ops
+    g = torch.Generator().manual_seed(11)
+    fi, ft = torch.randn(16, 128, generator=g), torch.randn(16, 128, generator=g)
+    mu, yy = torch.randn(16, 64, generator=g), torch.randn(16, 64, generator=g) + 0.5
+    fid, ftd = fi.cuda().requires_grad_(), ft.cuda().requires_grad_()
+    li, _ = ops.clip_loss(fid, ftd, 0.1, 0.5)
+    li.backward()
+    mud, yd = mu.cuda().requires_grad_(), yy.cuda().requires_grad_()
+    c, e = ops.ClubFn.apply(mud, yd)
+    (1.5 * c + 0.5 * e).backward()
+    close = lambda a, b, t=2e-6: float((a - b).abs().max()) <= t * (1 + float(b.abs().max()))
+    assert close(r0["itc"], li.detach().cpu()) and close(r1["itc"], li.detach().cpu())
+    assert close((r0["club"] + r1["club"]) / 2, c.detach().cpu()) and close((r0["est"] + r1["est"]) / 2, e.detach().cpu())
+    for key, ref in (("dfi", fid.grad), ("dft", ftd.grad), ("dmu", mud.grad), ("dy", yd.grad)):
+        got = torch.cat((r0[key], r1[key])) / 2
+        assert close(got, ref.cpu()), key
+    a, b = r0["buf"]
+    assert torch.equal(r0["params"][:a], r1["params"][:a]) and torch.equal(r0["params"][b:], r1["params"][b:]), "ranks diverged"
+    assert not torch.equal(r0["params"][a:b], r1["params"][a:b])  # BN running stats are per-shard until the next sync
+    assert torch.equal(r0["params_synced"], r1["params_synced"]) and torch.equal(r0["ema_synced"], r1["ema_synced"])
+    assert torch.equal(r0["params_synced"], r0["params"])  # rank 0 is the source
+    assert torch.equal(r0["grads"], r1["grads"]) and torch.equal(r0["psum"], r1["psum"])
     assert float((r0["grads"] - gsum).abs().max()) <= 1e-6 * (1 + scale)
     assert float((r0["psum"] - psum).abs().max()) <= 1e-5 and torch.equal(r0["pcnt"], pcnt)
 
@@ -115,8 +201,13 @@ def test_rccl_collectives_accept_the_slab_views():
     which still exercises RCCL's initialisation, stream hand-over and the tensor views it is given."""
     with tempfile.TemporaryDirectory() as td:
         ctx = mp.get_context("spawn")
-        p = ctx.Process(target=_nccl_worker, args=(29900 + os.getpid() % 90, td))
+        p = ctx.Process(target=_nccl_worker, args=(_free_port(), td))
         p.start()
         p.join(timeout=300)
+        if p.is_alive():
+            p.terminate(); p.join(timeout=10)
+            if p.is_alive():
+                p.kill(); p.join()
+            raise AssertionError("the RCCL worker hung and was killed: investigate from its output")
         assert p.exitcode == 0
         assert open(os.path.join(td, "ok")).read() == "1"

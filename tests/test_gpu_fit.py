@@ -64,7 +64,7 @@ def test_fit_checkpoint_reload_resume_and_test(tmp_path):
     vi, vt, vy = _data(40, 3)
     loaders = {"l": _Pairs(li, lt, ly, l_bs, True), "u": _Pairs(ui, ut, uy, u_bs, False)}
     val = _Val(vi, vt, vy, 16)
-    m = _model()
+    m = _model(warmup_epochs=1)
     m.setup_device("cuda")
     m.prototypes.copy_(torch.nn.functional.normalize(torch.randn(3, 128, generator=torch.Generator().manual_seed(5))).cuda())
     out = F.fit(m, loaders, val, max_epochs=4, eval_metric="acc", logdir=str(tmp_path), verbose=False)
@@ -76,7 +76,7 @@ def test_fit_checkpoint_reload_resume_and_test(tmp_path):
     assert ck["epoch"] == out["best_epoch"] and len(ck["optimizer_states"][0]["param_groups"]) == 6  # STiLModel.py:563-570
     assert any(k.startswith("ema.") for k in ck["state_dict"]) and "prototypes" in ck["state_dict"]
     # a fresh module + the checkpoint reproduces the best validation score exactly
-    m2 = _model()
+    m2 = _model(warmup_epochs=1)
     m2.setup_device("cuda")
     F.load_checkpoint(out["checkpoint"], m2)
     got = F.validate(m2, val)
@@ -84,9 +84,16 @@ def test_fit_checkpoint_reload_resume_and_test(tmp_path):
     res = F.test(m2, val, ckpt_path=out["checkpoint"])
     assert abs(res["test.acc"] - out["best_score"]) < 1e-7 and 0.0 <= res["test.auc"] <= 1.0
     # resume continues the epoch / step counters and restores Adam's moments
-    m3 = _model()
+    m3 = _model(warmup_epochs=1)
     out3 = F.fit(m3, loaders, val, max_epochs=ck["epoch"] + 2, logdir=str(tmp_path / "resumed"), resume_from=out["checkpoint"], verbose=False)
     assert out3["epochs_run"] == 1 and out3["global_step"] == ck["global_step"] + 4
+    # the resumed epoch trains with the learning rate an uninterrupted run uses for that epoch (Lightning steps the
+    # epoch-interval scheduler before validation / checkpointing: the checkpoint carries the NEXT epoch's rate)
+    e3 = ck["epoch"] + 1
+    m4 = _model(warmup_epochs=1)
+    out4 = F.fit(m4, loaders, val, max_epochs=e3 + 1, logdir=None, verbose=False)
+    assert list(out3["lr_by_epoch"]) == [e3] and out3["lr_by_epoch"][e3] == out4["lr_by_epoch"][e3]
+    assert len(set(out4["lr_by_epoch"].values())) == len(out4["lr_by_epoch"]), "the schedule must move for this to be a test"
     st = ck["optimizer_states"][0]["state"]
     steps = [float(v["step"]) for v in st.values()]  # heads that only feed the pseudo-label losses start one epoch later
     assert len(st) > 100 and max(steps) == ck["global_step"] and min(steps) >= ck["global_step"] - 4
