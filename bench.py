@@ -31,6 +31,13 @@ FLOPS_PER_SAMPLE = {(224, 64): 41.475e9, (128, 17): 13.155e9}  # SURVEY.md 8(d):
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
+def kernel_name(cfg: int) -> str:
+    """stil_gemm_nt_config code -> the template instantiation rocprofv3 lists."""
+    variant, bk32, acc2, vec = cfg % 100, (cfg // 100) % 10, (cfg // 1000) % 10, (cfg // 10000) % 10
+    tm, tn = {22: (2, 2), 21: (2, 1), 11: (1, 1)}[variant]
+    return f"gemm_nt_kernel<{tm}, {tn}, {32 if bk32 else 16}, {'true' if vec else 'false'}, {'true' if acc2 else 'false'}>"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -44,7 +51,8 @@ def parse():
     ap.add_argument("--variant", choices=["dvm", "saint", "cardiac", "mmatch"], default="dvm",
                     help="dvm = BASELINE configs[1..2] (the bench line); saint = config 4; cardiac = config 5 (26 cat + 49 con, K=2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--cpu-batch", type=int, default=32, help="batch of the CPU baseline (BASELINE.md section 3: 32; 256 = the bench's own batch, ~2 min per step)")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps after one warm-up (BASELINE.md section 3: >= 3)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (driver.GraphedTrainStep)")
     ap.add_argument("--host-input", action="store_true", help="every step's batch starts in pageable host memory and goes through "
                     "data.DevicePrefetcher (PCIe-inclusive rate; NOT the contract's `value`, which has inputs resident in HBM)")
@@ -52,7 +60,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(field_lengths, classes, img, batch, steps=2):
+def cpu_baseline(field_lengths, classes, img, batch, steps=3):
     """The oracle's full step (training_step + backward + Adam) on the host cores: a bounded sample of the workload."""
     from oracle import stil_oracle as O
     hp = O.default_hparams(field_lengths=field_lengths, num_classes=classes, img_size=img, batch_size=batch, start_epoch=0)
@@ -127,59 +135,68 @@ def main():
     for s in range(a.steps):
         if feed:
             batch = next(feed)
-        if s == a.steps - 2 and not a.graph:
-            L.begin_profile(single_stream=False, only=("gemm_nt",))  # second-to-last step: events around the GEMM launches, both streams running
-        if s == a.steps - 1:
-            if prof_conc is None and L._prof is not None:
-                torch.cuda.synchronize()
-                prof_conc = L.end_profile()
-            L.begin_profile(only=None if a.breakdown else ("gemm_nt", "wgrad_tn"))  # HIP events around the launches of the last timed step (one stream)
-        if a.graph and s == a.steps - 1:
-            eager_step(m, opt, batch)  # per-launch events need eager launches: the profiled last step runs eagerly
-        else:
-            train_step(m, opt, batch)
-        if s == a.steps - 1:
-            torch.cuda.synchronize()
-            prof = L.end_profile()
+        if s == a.steps - 1 and not a.graph:
+            # last timed step: HIP events around the GEMM launches only, on whichever stream they go to (both streams
+            # keep running: nothing about the step changes, the cost is two event records per launch)
+            L.begin_profile(single_stream=False, only=("gemm_nt",))
+        train_step(m, opt, batch)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if L._prof is not None:
+        prof_conc = L.end_profile()
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    # OUTSIDE the timed region: one more step with every launch kept on ONE stream and bracketed by HIP events -- clean
+    # per-kernel durations (no second kernel sharing the chip), which is what the roofline of the kernel is priced on
+    L.begin_profile(only=None if a.breakdown else ("gemm_nt", "wgrad_tn"))
+    (eager_step if a.graph else train_step)(m, opt, batch)
+    torch.cuda.synchronize()
+    prof = L.end_profile()
     loss = float(m.last["loss"].detach())
     assert loss == loss, "loss is NaN"
 
     if rank == 0:
         value = a.batch * world * a.steps / dt
-        # dominant kernel = the gemm_nt tile variant with the largest share of the step's GPU time
+        # dominant kernel = the gemm_nt instantiation with the largest share of the step's GPU time; meta[0] is the
+        # configuration the library reports for that very launch (stil_gemm_nt_config: tile, BK, vector loads, two-level sums)
         byvar = {}
         for name, ms, meta in prof:
             if name == "gemm_nt" and meta:
                 c = byvar.setdefault(meta[0], [0, 0.0, 0.0, 0.0])
                 c[0] += 1; c[1] += ms * 1e-3; c[2] += meta[1]; c[3] += meta[3]
         var, (nl, tsum, fsum, bsum) = max(byvar.items(), key=lambda kv: kv[1][1])
-        kname = {22: "gemm_nt_kernel<2, 2, 16, true>", 21: "gemm_nt_kernel<2, 1, 16, true>", 11: "gemm_nt_kernel<1, 1, 16, true>"}[var]
+        kname = kernel_name(var)
         achieved = fsum / tsum / 1e12 if tsum > 0 else 0.0
         roof = dict(bound="mfma", kernel=kname, achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS,
                     unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
                     launches_per_step=nl, avg_launch_us=round(tsum / max(1, nl) * 1e6, 2),
                     flops_per_step=fsum, share_of_step_time=round(tsum / (dt / a.steps), 4),
                     algorithmic_bytes=round(bsum / max(1, nl)),
-                    note="achieved / avg_launch_us: HIP events on the last timed step, which runs single-stream (agrees with "
-                         "profiles/*_single_stream.csv = this command with STIL_WGRAD_STREAM=0); two_stream: the same kernel on the "
-                         "second-to-last step while the side stream (EMA teacher, weight gradients) co-runs, which is what a "
-                         "rocprofv3 trace of the default command averages (profiles/*_bench_kernel_stats.csv)")
+                    all_gemm_nt={kernel_name(k): dict(launches=v[0], ms=round(v[1] * 1e3, 3), tflops=round(v[2] / v[1] / 1e12, 2)) for k, v in
+                                 sorted(byvar.items(), key=lambda kv: -kv[1][1])},
+                    note="achieved / avg_launch_us: HIP events around every launch of one extra step run right after the timed region "
+                         "with all launches on ONE stream (agrees with profiles/*_single_stream.csv = this command with "
+                         "STIL_WGRAD_STREAM=0); two_stream: the same kernel during the LAST TIMED step, while the side stream (EMA "
+                         "teacher, weight gradients) co-runs -- what a rocprofv3 trace of the default command averages "
+                         "(profiles/*_bench_kernel_stats.csv)")
         # HBM traffic of that kernel: PMC counters cannot be read from inside the process; the latest separate-pass
         # rocprofv3 measurement of this same command is kept under profiles/ and quoted when it is for this kernel.
         try:
-            pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_traffic.json"))
-            tj = json.load(open(os.path.join(ROOT, "profiles", pmc[-1]))) if pmc else None
+            pdir = os.path.join(ROOT, "profiles")
+            pmc = sorted(f for f in os.listdir(pdir) if f.endswith("pmc_traffic.json"))
+            tj = json.load(open(os.path.join(pdir, pmc[-1]))) if pmc else None
             if tj and tj["kernel"] == kname and a.batch == 256 and a.img == 224:
                 roof["traffic"] = round(tj["bytes_per_launch"])
                 roof["traffic_source"] = "profiles/" + pmc[-1]
+            mu = sorted(f for f in os.listdir(pdir) if f.endswith("mfma_util.json"))
+            uj = json.load(open(os.path.join(pdir, mu[-1]))) if mu else None
+            if uj and kname in uj.get("kernels", {}) and a.batch == 256 and a.img == 224:
+                roof["mfma_busy"] = uj["kernels"][kname]["mfma_busy_of_cu_busy"]
+                roof["mfma_busy_source"] = "profiles/" + mu[-1] + " (SQ_VALU_MFMA_BUSY_CYCLES / 4 / SQ_BUSY_CU_CYCLES, rocprofv3 --pmc on this command)"
         except Exception:
             pass
         if prof_conc:  # the same kernel while the second stream co-runs (what a rocprofv3 trace of this command averages)
@@ -207,7 +224,7 @@ def main():
         if a.breakdown:
             agg = {}
             for name, ms, meta in prof:
-                key = name if name != "gemm_nt" else f"gemm_nt<{meta[0]}>"
+                key = name if name != "gemm_nt" else kernel_name(meta[0])
                 c = agg.setdefault(key, [0, 0.0])
                 c[0] += 1; c[1] += ms
             tot = sum(v[1] for v in agg.values())
@@ -223,7 +240,7 @@ def main():
             for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:60]:
                 print(f"    {str(k):44s} {v[0]:3d} {v[1]:8.3f} ms {v[2] / v[1] / 1e9:7.1f} TF", file=sys.stderr)
         if world == 1 and not a.no_cpu_baseline and a.variant == "dvm":
-            out["cpu_baseline"] = cpu_baseline(fl, a.classes, a.img, a.cpu_batch)
+            out["cpu_baseline"] = cpu_baseline(fl, a.classes, a.img, a.cpu_batch, max(1, a.cpu_steps))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -55,6 +55,8 @@ int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, 
  * rows per output tile / tile variant stil_gemm_nt uses for an [M,N] output under `tune` (colstats granularity, bench bookkeeping) */
 int stil_gemm_nt_tile_rows(int M, int N, int tune);
 int stil_gemm_nt_variant(int M, int N, int tune);
+/* the instantiation stil_gemm_nt launches for these operands: variant + 100 * bk32 + 1000 * acc2 + 10000 * vec (16-byte loads) */
+int stil_gemm_nt_config(const float* A, const float* W, int M, int N, int K, int lda, int ldb, int srcC, int KH, int KW, int tune);
 
 /* Weight gradient  dW (+)= dY[M,N]^T . Xgather[M,K]  (split over M, slab partials + ordered reduce).
  * KH*KW > 1: dW is written in the reference layout (N, srcC, KH, KW); else [N, Kdst] (first Kdst columns).
@@ -231,6 +233,31 @@ int stil_metric_binary(const float* probs, const long long* target, int N, float
 size_t stil_auroc_workspace_bytes(int N, int K);
 int stil_auroc(const float* scores, int ld, const long long* target, int N, int K, float* auc_per_class, float* macro,
                void* ws, size_t ws_bytes, void* stream);
+
+/* ---- device input pipeline ---------------------------------------------------------------
+ * Batch versions of what the reference's DataLoader workers compute per sample on the CPU.  Random draws are
+ * arguments (drawn by the host wrapper stil_tta_amd/augment.py, or injected by tests).
+ *
+ * stil_tab_corrupt: ContrastiveImagingAndTabularDataset.corrupt (datasets/ContrastiveImagingAndTabularDataset.py:146-158):
+ *   out[b,:] = clean[b,:]; out[b, idx[b,j]] = marginal[idx[b,j], pos[b,j]], j < k = int(n_cols * corruption_rate);
+ *   marginal [n_cols, n_rows] = the training table transposed (:121-127); idx rows hold DISTINCT columns (random.sample).
+ * stil_tab_corrupt_draw: those draws on the device (partial Fisher-Yates + uniform rows, counter-based hash RNG;
+ *   `step` = optional device-side step counter so that hipGraph replays draw fresh values). */
+int stil_tab_corrupt(const float* clean, const float* marginal, const int* idx, const int* pos, float* out,
+                     int B, int n_cols, int n_rows, int k, void* stream);
+int stil_tab_corrupt_draw(int* idx, int* pos, int B, int n_cols, int n_rows, int k, unsigned long long seed,
+                          unsigned long long offset, const unsigned long long* step, void* stream);
+/* stil_aug_resize: crop box[b] = (top, left, h, w) -> bilinear resize to P x P (half-pixel centres, no antialias) ->
+ *   optional horizontal flip -> optional colour (jitter[b] = brightness, contrast, saturation, gray flag; torchvision's
+ *   float formulas in that order) -> * scale -> clip [0,1] -> float CHW [B,3,P,P].  Source: uint8 HWC [B,H,W,3] or float
+ *   CHW [B,3,H,W] (exactly one non-null).  Replaces RandomResizedCrop / Resize / HorizontalFlip / ColorJitter / ToGray /
+ *   convert_to_ts of utils/utils.py:33-59 and ContrastiveImagingAndTabularDataset.py:177-198 (GaussianBlur is not built).
+ * stil_aug_gray_mean: per-sample mean grey level of the brightness-adjusted source image (what adjust_contrast blends with). */
+int stil_aug_gray_mean(const unsigned char* src_u8, const float* src_f32, const float* jitter, float* gmean, int B, int H,
+                       int W, float scale, void* stream);
+int stil_aug_resize(const unsigned char* src_u8, const float* src_f32, const int* box, const unsigned char* flip,
+                    const float* jitter, const float* gmean, float* out, int B, int H, int W, int P, float scale,
+                    void* stream);
 
 #ifdef __cplusplus
 }

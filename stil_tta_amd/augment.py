@@ -1,0 +1,173 @@
+"""Device input pipeline: the per-sample CPU work of the reference's DataLoader workers
+(datasets/ContrastiveImagingAndTabularDataset.py:146-213, utils/utils.py:46-70) as a few batch launches on data that is
+already resident in HBM -- the table, its transposed marginals and the uint8 images of one GPU's shard fit easily in
+288 GB, so nothing but the batch's row indices crosses PCIe per step.
+
+    builder = ContrastiveBatchBuilder(images_u8 [N,H,W,3], table [N,n_cols], labels [N], img_size=128, target="dvm",
+                                      corruption_rate=0.3, augmentation_rate=0.95, labelled=True)
+    batch_part = builder(index_tensor)          # -> (im_views, tab_views, y, orig_im, identify), SURVEY.md 8b
+
+Random draws are made here (numpy Generator on the host for the few scalars per image, the hash RNG of
+stil_tab_corrupt_draw for the table) or injected (`draws=`) by the parity tests.  What is pinned to the reference:
+`corrupt` (golden vectors recorded from the reference's own method).  The image transforms follow torchvision's float
+tensor formulas (the reference's non-`augmentation_speedup` branch); albumentations / cv2 / torchvision are absent
+offline, so they are tested against PyTorch restatements only (unpinned), and GaussianBlur is not built.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from ._lib import lib
+from .ops import _p, _stream, _chk
+
+
+def rrc_boxes(H: int, W: int, B: int, scale=(0.08, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0), rng: Optional[np.random.Generator] = None) -> np.ndarray:
+    """torchvision RandomResizedCrop.get_params for B images at once -> int32 [B, 4] (top, left, height, width):
+    up to 10 attempts of area ~ U(scale) * H * W, log-uniform aspect ratio; fallback = central crop at the clamped ratio."""
+    rng = rng or np.random.default_rng()
+    area = float(H * W)
+    out = np.zeros((B, 4), dtype=np.int32)
+    done = np.zeros(B, dtype=bool)
+    lo, hi = math.log(ratio[0]), math.log(ratio[1])
+    for _ in range(10):
+        ta = area * rng.uniform(scale[0], scale[1], size=B)
+        ar = np.exp(rng.uniform(lo, hi, size=B))
+        w = np.rint(np.sqrt(ta * ar)).astype(np.int64)
+        h = np.rint(np.sqrt(ta / ar)).astype(np.int64)
+        ok = (~done) & (w > 0) & (w <= W) & (h > 0) & (h <= H)
+        top = (rng.random(B) * (H - np.minimum(h, H) + 1)).astype(np.int64)
+        left = (rng.random(B) * (W - np.minimum(w, W) + 1)).astype(np.int64)
+        out[ok] = np.stack([top, left, h, w], 1)[ok]
+        done |= ok
+    if not done.all():  # fallback: whole image clamped to the ratio range, centred
+        in_ratio = W / H
+        if in_ratio < ratio[0]:
+            w, h = W, int(round(W / ratio[0]))
+        elif in_ratio > ratio[1]:
+            h, w = H, int(round(H * ratio[1]))
+        else:
+            w, h = W, H
+        out[~done] = np.array([(H - h) // 2, (W - w) // 2, h, w], dtype=np.int32)
+    return out
+
+
+class TabularCorruptor:
+    """`corrupt` (ContrastiveImagingAndTabularDataset.py:146-158) for a batch: k = int(n_cols * corruption_rate) distinct
+    columns of every row are replaced by the value of a uniformly drawn training row in that column."""
+
+    def __init__(self, table: torch.Tensor, corruption_rate: float, device, seed: int = 2022):
+        table = torch.as_tensor(table, dtype=torch.float32)
+        self.n_rows, self.n_cols = table.shape
+        self.marginal = table.t().contiguous().to(device)   # generate_marginal_distributions: the table transposed
+        self.k = int(self.n_cols * corruption_rate)
+        self.seed, self.calls = int(seed), 0
+
+    def draw(self, B: int):
+        dev = self.marginal.device
+        idx = torch.empty((B, max(self.k, 1)), dtype=torch.int32, device=dev)
+        pos = torch.empty((B, max(self.k, 1)), dtype=torch.int32, device=dev)
+        if self.k:
+            lib().tab_corrupt_draw(_p(idx), _p(pos), B, self.n_cols, self.n_rows, self.k, self.seed, self.calls * B * 2 * self.k, None, _stream())
+        self.calls += 1
+        return idx, pos
+
+    def __call__(self, clean: torch.Tensor, draws=None) -> torch.Tensor:
+        _chk(clean)
+        B = clean.shape[0]
+        idx, pos = self.draw(B) if draws is None else (draws[0].to(clean.device, torch.int32).contiguous(), draws[1].to(clean.device, torch.int32).contiguous())
+        out = torch.empty_like(clean)
+        lib().tab_corrupt(_p(clean), _p(self.marginal), _p(idx), _p(pos), _p(out), B, self.n_cols, self.n_rows, self.k, _stream())
+        return out
+
+
+def resize_crop(src: torch.Tensor, boxes, P: int, flip=None, jitter=None) -> torch.Tensor:
+    """src: uint8 [B,H,W,3] (scaled by 1/255 like convert_to_ts) or float [B,3,H,W]; boxes int32 [B,4] (top, left, h, w);
+    flip uint8 [B]; jitter float [B,4] = (brightness, contrast, saturation, gray).  -> float [B,3,P,P] in [0,1]."""
+    _chk(src)
+    dev = src.device
+    u8 = src.dtype == torch.uint8
+    B = src.shape[0]
+    H, W = (src.shape[1], src.shape[2]) if u8 else (src.shape[2], src.shape[3])
+    scale = 1.0 / 255.0 if u8 else 1.0
+    boxes = torch.as_tensor(boxes, dtype=torch.int32).to(dev).contiguous()
+    b = boxes.cpu() if boxes.is_cuda and boxes.numel() <= 4096 else None
+    if b is not None and not bool(((b[:, 0] >= 0) & (b[:, 1] >= 0) & (b[:, 2] > 0) & (b[:, 3] > 0) & (b[:, 0] + b[:, 2] <= H) & (b[:, 1] + b[:, 3] <= W)).all()):
+        raise ValueError("crop box outside the source image")   # the kernel trusts the boxes: check them on the host
+    flip = None if flip is None else torch.as_tensor(flip).to(dev, torch.uint8).contiguous()
+    gmean = None
+    if jitter is not None:
+        jitter = torch.as_tensor(jitter, dtype=torch.float32).to(dev).contiguous()
+        gmean = torch.empty((B,), dtype=torch.float32, device=dev)
+        lib().aug_gray_mean(_p(src) if u8 else None, None if u8 else _p(src), _p(jitter), _p(gmean), B, H, W, scale, _stream())
+    out = torch.empty((B, 3, P, P), dtype=torch.float32, device=dev)
+    lib().aug_resize(_p(src) if u8 else None, None if u8 else _p(src), _p(boxes), _p(flip), _p(jitter), _p(gmean), _p(out), B, H, W, P, scale,
+                     _stream())
+    return out
+
+
+class ImageAugmenter:
+    """grab_image_augmentations (utils/utils.py:46-91) + default_transform (ContrastiveImagingAndTabularDataset.py:66-90):
+    dvm: ColorJitter(0.8, 0.8, 0.8) p=0.8, ToGray p=0.2, RandomResizedCrop(scale=(0.08, 1), ratio=(3/4, 4/3)), HFlip p=0.5;
+    cardiac: HFlip p=0.5, ColorJitter(0.5, 0.5, 0.5), RandomResizedCrop(scale=(0.2, 1)).  (GaussianBlur / Rotate: not built.)
+    Every image is augmented with probability `augmentation_rate`, otherwise only resized (generate_imaging_views)."""
+
+    def __init__(self, img_size: int, target: str = "dvm", augmentation_rate: float = 1.0, seed: int = 2022):
+        self.P, self.dvm, self.rate = int(img_size), target.lower() == "dvm", float(augmentation_rate)
+        self.rng = np.random.default_rng(seed)
+
+    def draw(self, B: int, H: int, W: int) -> Dict[str, np.ndarray]:
+        r = self.rng
+        aug = r.random(B) < self.rate
+        boxes = rrc_boxes(H, W, B, scale=(0.08, 1.0) if self.dvm else (0.2, 1.0), rng=r)
+        boxes[~aug] = np.array([0, 0, H, W], dtype=np.int32)
+        flip = ((r.random(B) < 0.5) & aug).astype(np.uint8)
+        amt = 0.8 if self.dvm else 0.5
+        jit = np.ones((B, 4), dtype=np.float32)
+        on = aug & ((r.random(B) < 0.8) if self.dvm else np.ones(B, dtype=bool))
+        jit[:, :3] = np.where(on[:, None], r.uniform(max(0.0, 1.0 - amt), 1.0 + amt, size=(B, 3)), 1.0)
+        jit[:, 3] = ((r.random(B) < 0.2) & aug).astype(np.float32) if self.dvm else 0.0
+        return dict(boxes=boxes, flip=flip, jitter=jit)
+
+    def __call__(self, src: torch.Tensor, draws: Optional[Dict[str, np.ndarray]] = None):
+        """-> (augmented view, unaugmented resized image), both float [B,3,P,P]."""
+        u8 = src.dtype == torch.uint8
+        B = src.shape[0]
+        H, W = (src.shape[1], src.shape[2]) if u8 else (src.shape[2], src.shape[3])
+        d = draws or self.draw(B, H, W)
+        view = resize_crop(src, d["boxes"], self.P, d.get("flip"), d.get("jitter"))
+        full = np.tile(np.array([[0, 0, H, W]], dtype=np.int32), (B, 1))
+        return view, resize_crop(src, full, self.P)
+
+
+class ContrastiveBatchBuilder:
+    """ContrastiveImagingAndTabularDataset.__getitem__ + default_collate for a batch of row indices, on the device:
+    -> (im_views = [placeholder [b], augmented [b,3,P,P]], tab_views = [clean [b,n], corrupted [b,n]], y [b] int64,
+        orig_im [b,3,P,P], identify [b] bool)  -- the part tuple STiLModel.training_step consumes."""
+
+    def __init__(self, images: torch.Tensor, table: torch.Tensor, labels: torch.Tensor, img_size: int, target: str = "dvm",
+                 corruption_rate: float = 0.3, augmentation_rate: float = 0.95, labelled: bool = True, device="cuda", seed: int = 2022):
+        self.images = images.to(device)                      # uint8 [N,H,W,3] or float [N,3,H,W], resident in HBM
+        self.table = torch.as_tensor(table, dtype=torch.float32).to(device)
+        self.labels = torch.as_tensor(labels, dtype=torch.int64).to(device)
+        assert len(self.images) == len(self.table) == len(self.labels)
+        self.corrupt = TabularCorruptor(self.table, corruption_rate, device, seed)
+        self.augment = ImageAugmenter(img_size, target, augmentation_rate, seed + 1)
+        self.labelled = bool(labelled)
+
+    def __len__(self):
+        return len(self.labels)
+
+    def __call__(self, index: torch.Tensor, draws=None):
+        index = torch.as_tensor(index).to(self.table.device, torch.int64)
+        b = len(index)
+        clean = self.table.index_select(0, index)
+        src = self.images.index_select(0, index)
+        view, orig = self.augment(src, None if draws is None else draws.get("image"))
+        corrupted = self.corrupt(clean, None if draws is None else draws.get("table"))
+        dev = self.table.device
+        return ([torch.zeros(b, device=dev), view], [clean, corrupted], self.labels.index_select(0, index), orig,
+                torch.full((b,), self.labelled, dtype=torch.bool, device=dev))

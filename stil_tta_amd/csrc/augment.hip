@@ -1,0 +1,194 @@
+// Device side of the input pipeline: what the reference's DataLoader workers do per sample on
+// the CPU -- datasets/ContrastiveImagingAndTabularDataset.py:146-158 (marginal-distribution tabular corruption),
+// :177-198 + utils/utils.py:46-70 (RandomResizedCrop / Resize, HorizontalFlip, ColorJitter, ToGray, convert_to_ts) --
+// as batch kernels.  All of it is HBM-bound byte/float shuffling: coalesced channel-plane writes, one launch per batch.
+// Random draws are ARGUMENTS (boxes, flips, factors, column indices, table rows): the host wrapper draws them (or the
+// tests inject them), so results are reproducible and the kernels are pure functions.
+#include "common.h"
+
+// ---------------------------------------------------------------- tabular corruption
+// out[b, :] = clean[b, :];  out[b, idx[b, j]] = marginal[idx[b, j], pos[b, j]]  for j < k
+// (marginal = the training table transposed: [n_cols, n_rows], ContrastiveImagingAndTabularDataset.py:121-127).
+__global__ __launch_bounds__(64) void tab_corrupt_kernel(const float* __restrict__ clean, const float* __restrict__ marginal,
+                                                          const int* __restrict__ idx, const int* __restrict__ pos,
+                                                          float* __restrict__ out, int n, int N, int k) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < n; c += 64) out[(long)b * n + c] = clean[(long)b * n + c];
+  __syncthreads();   // same block wrote the row: the scatter below lands after the copy
+  for (int j = threadIdx.x; j < k; j += 64) {
+    const int c = idx[(long)b * k + j];
+    out[(long)b * n + c] = marginal[(long)c * N + pos[(long)b * k + j]];
+  }
+}
+
+// counter-based hash RNG (same family as rng_mask_kernel): uniform 32-bit word for (seed, counter)
+__device__ __forceinline__ unsigned int aug_hash(unsigned long long seed, unsigned long long ctr) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ULL * (ctr + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  z ^= z >> 31;
+  return (unsigned int)(z >> 16);
+}
+
+// Draws of `corrupt` on the device: per row k DISTINCT columns (partial Fisher-Yates: random.sample semantics) and k
+// uniform table rows (np.random.choice with replacement).  One wave per row, lane 0 walks the permutation in LDS.
+__global__ __launch_bounds__(64) void tab_corrupt_draw_kernel(int* __restrict__ idx, int* __restrict__ pos, int n, int N, int k,
+                                                               unsigned long long seed, unsigned long long offset,
+                                                               const unsigned long long* __restrict__ step) {
+  extern __shared__ int perm[];
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < n; c += 64) perm[c] = c;
+  __syncthreads();
+  const unsigned long long base = offset + (step ? step[0] : 0ULL) * 0x100000000ULL + (unsigned long long)b * (2ULL * k);
+  if (threadIdx.x == 0) {
+    for (int j = 0; j < k; ++j) {
+      const int r = j + (int)(((unsigned long long)aug_hash(seed, base + j) * (unsigned long long)(n - j)) >> 32);
+      const int t = perm[j]; perm[j] = perm[r]; perm[r] = t;
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < k; j += 64) {
+    idx[(long)b * k + j] = perm[j];
+    pos[(long)b * k + j] = (int)(((unsigned long long)aug_hash(seed, base + k + j) * (unsigned long long)N) >> 32);
+  }
+}
+
+// ---------------------------------------------------------------- crop + resize + flip + (colour) + to-tensor
+// One output pixel per thread, all 3 channels.  Source: uint8 HWC [B, H, W, 3] (the `.npy` images the reference loads
+// with augmentation_speedup) or float CHW [B, 3, H, W].  box[b] = (top, left, height, width) of the crop in source
+// pixels (RandomResizedCrop.get_params; the whole image for the plain Resize of default_transform), flip[b] != 0
+// mirrors the crop horizontally.  Bilinear with half-pixel centres, no antialias (torchvision 0.12 tensor resize ==
+// F.interpolate(mode="bilinear", align_corners=False)): src = (dst + 0.5) * in/out - 0.5, clamped at 0; the right /
+// bottom neighbour is clamped to the crop.  Colour (optional, per sample, utils/utils.py:50-52): jitter[b] =
+// (brightness, contrast, saturation, gray) applied as torchvision's float ops in the fixed order brightness ->
+// contrast -> saturation -> grayscale; contrast needs the mean grey level of the (brightness-adjusted) source image,
+// which the host passes as gmean[b] (stil_aug_gray_mean).  The pointwise colour ops run on the resized crop (the
+// reference jitters before it crops; the two orders differ only where the [0, 1] clamp is active).  Output float CHW [B, 3, P, P], values scaled by `scale` (1/255 for
+// uint8 sources: convert_to_ts) and clipped to [0, 1] like the reference's np.clip.
+struct AugArgs {
+  const unsigned char* src_u8; const float* src_f32;
+  const int* box; const unsigned char* flip; const float* jitter; const float* gmean;
+  float* out; int H, W, P; float scale;
+};
+
+__device__ __forceinline__ void aug_fetch(const AugArgs& p, int b, int y, int x, float (&v)[3]) {
+  if (p.src_u8) {
+    const unsigned char* q = p.src_u8 + (((long)b * p.H + y) * p.W + x) * 3;
+    v[0] = (float)q[0]; v[1] = (float)q[1]; v[2] = (float)q[2];
+  } else {
+    const long plane = (long)p.H * p.W;
+    const float* q = p.src_f32 + (long)b * 3 * plane + (long)y * p.W + x;
+    v[0] = q[0]; v[1] = q[plane]; v[2] = q[2 * plane];
+  }
+}
+
+__device__ __forceinline__ void aug_sample(const AugArgs& p, int b, int oy, int ox, float (&rgb)[3]) {
+  const int top = p.box[b * 4 + 0], left = p.box[b * 4 + 1], ch = p.box[b * 4 + 2], cw = p.box[b * 4 + 3];
+  if (p.flip && p.flip[b]) ox = p.P - 1 - ox;   // flipping the output == flipping the crop before the resize
+  const float sy = (float)ch / (float)p.P, sx = (float)cw / (float)p.P;
+  float fy = ((float)oy + 0.5f) * sy - 0.5f, fx = ((float)ox + 0.5f) * sx - 0.5f;
+  fy = fy < 0.f ? 0.f : fy; fx = fx < 0.f ? 0.f : fx;
+  const int y0 = min((int)fy, ch - 1), x0 = min((int)fx, cw - 1);
+  const int y1 = min(y0 + 1, ch - 1), x1 = min(x0 + 1, cw - 1);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  float a[3], bb[3], c[3], d[3];
+  aug_fetch(p, b, top + y0, left + x0, a); aug_fetch(p, b, top + y0, left + x1, bb);
+  aug_fetch(p, b, top + y1, left + x0, c); aug_fetch(p, b, top + y1, left + x1, d);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float t0 = a[k] + lx * (bb[k] - a[k]), t1 = c[k] + lx * (d[k] - c[k]);
+    rgb[k] = (t0 + ly * (t1 - t0)) * p.scale;
+  }
+}
+
+__device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
+__device__ __forceinline__ float gray_of(const float (&v)[3]) { return 0.2989f * v[0] + 0.587f * v[1] + 0.114f * v[2]; }
+
+__global__ __launch_bounds__(256) void aug_resize_kernel(AugArgs p) {
+  const int b = blockIdx.y;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= p.P * p.P) return;
+  const int oy = pix / p.P, ox = pix - oy * p.P;
+  float v[3];
+  aug_sample(p, b, oy, ox, v);
+  if (p.jitter) {
+    const float br = p.jitter[b * 4 + 0], ct = p.jitter[b * 4 + 1], sa = p.jitter[b * 4 + 2], gr = p.jitter[b * 4 + 3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] = clamp01(v[k] * br);                                  // adjust_brightness: blend with 0
+    const float m = p.gmean ? p.gmean[b] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] = clamp01(ct * v[k] + (1.f - ct) * m);                 // adjust_contrast: blend with the mean grey
+    const float g = gray_of(v);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] = clamp01(sa * v[k] + (1.f - sa) * g);                 // adjust_saturation: blend with grey
+    if (gr != 0.f) { const float g2 = gray_of(v); v[0] = v[1] = v[2] = g2; }                // RandomGrayscale / ToGray
+  }
+  const long plane = (long)p.P * p.P;
+  float* o = p.out + (long)b * 3 * plane + pix;
+  o[0] = clamp01(v[0]); o[plane] = clamp01(v[1]); o[2 * plane] = clamp01(v[2]);
+}
+
+// mean grey level of the brightness-adjusted SOURCE image, per sample (the constant adjust_contrast blends with; the
+// reference jitters the whole image before it crops): one block per sample, fixed-order reduction (deterministic)
+__global__ __launch_bounds__(256) void aug_gray_mean_kernel(AugArgs p, float* __restrict__ gmean) {
+  __shared__ float red[16];
+  const int b = blockIdx.x;
+  const float br = p.jitter ? p.jitter[b * 4 + 0] : 1.f;
+  float s = 0.f;
+  for (int pix = threadIdx.x; pix < p.H * p.W; pix += 256) {
+    float v[3];
+    aug_fetch(p, b, pix / p.W, pix % p.W, v);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] = clamp01(v[k] * p.scale * br);
+    s += gray_of(v);
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) gmean[b] = s / (float)(p.H * p.W);
+}
+
+// ---------------------------------------------------------------- C ABI
+extern "C" int stil_tab_corrupt(const float* clean, const float* marginal, const int* idx, const int* pos, float* out,
+                                int B, int n_cols, int n_rows, int k, void* stream) {
+  STIL_REQUIRE(clean && marginal && out && B > 0 && n_cols > 0 && n_rows > 0, "stil_tab_corrupt: null pointer or empty shape");
+  STIL_REQUIRE(k >= 0 && k <= n_cols && (k == 0 || (idx && pos)), "stil_tab_corrupt: k=%d outside [0, %d] or missing draws", k, n_cols);
+  hipLaunchKernelGGL(tab_corrupt_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, clean, marginal, idx, pos, out, n_cols, n_rows, k);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" int stil_tab_corrupt_draw(int* idx, int* pos, int B, int n_cols, int n_rows, int k, unsigned long long seed,
+                                     unsigned long long offset, const unsigned long long* step, void* stream) {
+  STIL_REQUIRE(idx && pos && B > 0 && k > 0 && k <= n_cols && n_rows > 0, "stil_tab_corrupt_draw: bad arguments (k=%d, n_cols=%d)", k, n_cols);
+  STIL_REQUIRE(n_cols <= 8192, "stil_tab_corrupt_draw: n_cols=%d > 8192", n_cols);
+  hipLaunchKernelGGL(tab_corrupt_draw_kernel, dim3(B), dim3(64), n_cols * sizeof(int), (hipStream_t)stream, idx, pos, n_cols, n_rows, k,
+                     seed, offset, step);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+static int aug_check(const AugArgs& p, int B) {
+  STIL_REQUIRE((p.src_u8 != nullptr) != (p.src_f32 != nullptr), "stil_aug_resize: exactly one of src_u8 / src_f32");
+  STIL_REQUIRE(p.box && p.out && B > 0 && p.H > 0 && p.W > 0 && p.P > 0, "stil_aug_resize: null pointer or empty shape");
+  return STIL_OK;
+}
+
+extern "C" int stil_aug_gray_mean(const unsigned char* src_u8, const float* src_f32, const float* jitter, float* gmean, int B, int H,
+                                  int W, float scale, void* stream) {
+  AugArgs p{src_u8, src_f32, nullptr, nullptr, jitter, nullptr, nullptr, H, W, 1, scale};
+  STIL_REQUIRE((src_u8 != nullptr) != (src_f32 != nullptr) && gmean && B > 0 && H > 0 && W > 0, "stil_aug_gray_mean: bad arguments");
+  hipLaunchKernelGGL(aug_gray_mean_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, p, gmean);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" int stil_aug_resize(const unsigned char* src_u8, const float* src_f32, const int* box, const unsigned char* flip,
+                               const float* jitter, const float* gmean, float* out, int B, int H, int W, int P, float scale,
+                               void* stream) {
+  AugArgs p{src_u8, src_f32, box, flip, jitter, gmean, out, H, W, P, scale};
+  int rc = aug_check(p, B);
+  if (rc) return rc;
+  STIL_REQUIRE(!jitter || gmean, "stil_aug_resize: colour jitter needs gmean (stil_aug_gray_mean)");
+  hipLaunchKernelGGL(aug_resize_kernel, dim3(cdiv((long)P * P, 256), B), dim3(256), 0, (hipStream_t)stream, p);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}

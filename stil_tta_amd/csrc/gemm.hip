@@ -587,6 +587,17 @@ extern "C" int stil_gemm_nt_variant(int M, int N, int tune) {
 // rows per output tile of the variant stil_gemm_nt picks for [M,N] (the granularity of `colstats`)
 extern "C" int stil_gemm_nt_tile_rows(int M, int N, int tune) { return stil_gemm_nt_variant(M, N, tune) == 11 ? 64 : 128; }
 
+// The kernel instantiation stil_gemm_nt launches for these operands, as variant + 100 * bk32 + 1000 * acc2 + 10000 * vec
+// (bench bookkeeping: names the rocprofv3 row of a launch).  The launcher below calls the same function.
+extern "C" int stil_gemm_nt_config(const float* A, const float* W, int M, int N, int K, int lda, int ldb, int srcC, int KH, int KW,
+                                   int tune) {
+  const int variant = stil_gemm_nt_variant(M, N, tune);
+  const bool bk32 = (tune / 100) % 10 == 1 && (K % 32 == 0) && (KH * KW == 1 || srcC % 32 == 0);
+  const bool acc2 = tune / 1000 == 2 || (tune / 1000 == 0 && K >= 512);
+  const bool vec = is_vec(A, lda) && (srcC % 4 == 0) && is_vec(W, ldb) && (K % 4 == 0);  // every 16-byte load aligned and entirely in or out
+  return variant + 100 * ((vec && bk32) ? 1 : 0) + 1000 * (acc2 ? 1 : 0) + 10000 * (vec ? 1 : 0);
+}
+
 extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                             int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad_y,
                             int pad_x, int mode, int out_stride, int out_py, int out_px, int out_OH, int out_OW,
@@ -612,13 +623,13 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   int rc = check_geom(p.g, 0);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  const int variant = stil_gemm_nt_variant(M, N, tune);
-  // BK = 32 halves the barriers per MFMA and doubles the latency cover of the register prefetch; needs whole taps
-  const bool bk32 = (tune / 100) % 10 == 1 && (K % 32 == 0) && (KH * KW == 1 || srcC % 32 == 0);
+  const int cfg = stil_gemm_nt_config(A, W, M, N, K, lda, ldb, srcC, KH, KW, tune);
+  const int variant = cfg % 100;
+  const bool bk32 = (cfg / 100) % 10 == 1;   // BK = 32 halves the barriers per MFMA; needs whole taps and vector loads
+  const bool acc2 = (cfg / 1000) % 10 == 1;  // long reductions: two-level accumulation (see gemm_nt_kernel)
+  const bool vec = (cfg / 10000) % 10 == 1;
   rc = gemm_nt_attr();
   if (rc) return rc;
-  const bool vec = p.vecA && p.vecB && (K % 4 == 0);  // every 16-byte load is aligned and entirely in or out
-  const bool acc2 = tune / 1000 == 2 || (tune / 1000 == 0 && K >= 512);   // long reductions: two-level accumulation (see gemm_nt_kernel)
 #define LAUNCH_NT(TM_, TN_, BK_, V_)                                                                          \
   do {                                                                                                        \
     const dim3 grid_(cdiv(M, 64 * TM_) * cdiv(N, 64 * TN_));                                                  \

@@ -24,3 +24,4 @@ extern "C" int stil_device_count(void) {
 #include "loss.hip"
 #include "saint.hip"
 #include "optim.hip"
+#include "augment.hip"

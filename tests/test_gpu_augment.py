@@ -1,0 +1,138 @@
+"""Device input pipeline (stil_tta_amd/augment.py, csrc/augment.hip).
+Tabular corruption is pinned to golden vectors recorded from the REFERENCE's own `corrupt`
+(tests/golden/tab_corrupt.npz, oracle/make_golden_data.py): bit-exact with the reference's draws injected.
+The image transforms are checked against PyTorch-CPU restatements of torchvision's tensor formulas (torchvision and
+albumentations are absent offline: unpinned)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "tab_corrupt.npz")
+
+
+def test_tab_corrupt_matches_reference_golden_bit_for_bit():
+    from stil_tta_amd.augment import TabularCorruptor
+    fx = np.load(GOLD)
+    table = torch.tensor(fx["table"], dtype=torch.float32)
+    for tag, c in (("c030", 0.3), ("c000", 0.0), ("c100", 1.0), ("c005", 0.05)):
+        cor = TabularCorruptor(table, c, "cuda")
+        assert cor.k == fx[tag + "_idx"].shape[1]
+        clean = table[torch.arange(12) % len(table)].cuda()
+        got = cor(clean, draws=(torch.tensor(fx[tag + "_idx"]), torch.tensor(fx[tag + "_pos"])))
+        assert torch.equal(got.cpu(), torch.tensor(fx[tag + "_out"], dtype=torch.float32)), tag   # bit-exact (values are copied)
+        assert torch.equal(clean.cpu(), table[torch.arange(12) % len(table)])                       # the clean view is untouched
+
+
+def test_tab_corrupt_device_draws_are_valid_and_uniform():
+    from stil_tta_amd.augment import TabularCorruptor
+    g = torch.Generator().manual_seed(0)
+    table = torch.randn(500, 64, generator=g)
+    cor = TabularCorruptor(table, 0.3, "cuda", seed=7)
+    B = 4096
+    idx, pos = cor.draw(B)
+    idx, pos = idx.cpu().long(), pos.cpu().long()
+    assert idx.shape == (B, 19) and int(idx.min()) >= 0 and int(idx.max()) < 64 and int(pos.min()) >= 0 and int(pos.max()) < 500
+    assert all(len(set(r.tolist())) == 19 for r in idx[:512]), "columns of one row must be distinct (random.sample)"
+    col_freq = torch.bincount(idx.flatten(), minlength=64).float() / (B * 19)
+    assert float((col_freq - 1 / 64).abs().max()) < 0.15 / 64 * 4          # every column is picked about equally often
+    row_freq = torch.bincount(pos.flatten(), minlength=500).float() / (B * 19)
+    assert float((row_freq - 1 / 500).abs().max()) < 1 / 500
+    idx2, _ = cor.draw(B)
+    assert not torch.equal(idx2.cpu().long(), idx), "successive batches must draw fresh values"
+    # end to end: exactly k entries of every row come from the marginal of their own column, the rest are untouched
+    clean = table[:B % 500 + 300].cuda()
+    out = cor(clean).cpu()
+    changed = (out != clean.cpu())
+    assert int(changed.sum(1).max()) <= 19
+    cols = changed.nonzero()
+    for r, c in cols[:200].tolist():
+        assert bool((table[:, c] == out[r, c]).any())
+
+
+def _ref_resize(src_f, box, P, flip):
+    """crop -> F.interpolate(bilinear, align_corners=False) -> flip: torchvision's tensor resized_crop + hflip."""
+    t, l, h, w = [int(v) for v in box]
+    crop = src_f[:, t:t + h, l:l + w].unsqueeze(0)
+    out = F.interpolate(crop, size=(P, P), mode="bilinear", align_corners=False)[0]
+    return out.flip(-1) if flip else out
+
+
+def test_resize_crop_flip_matches_interpolate():
+    from stil_tta_amd.augment import resize_crop, rrc_boxes
+    g = torch.Generator().manual_seed(1)
+    B, H, W, P = 6, 97, 83, 64
+    u8 = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
+    boxes = rrc_boxes(H, W, B, rng=np.random.default_rng(3))
+    boxes[0] = [0, 0, H, W]           # the plain Resize of default_transform
+    boxes[1] = [5, 7, 1, 1]           # degenerate one-pixel crop
+    boxes[2] = [0, 0, 32, 32]         # upsampling
+    flip = np.array([0, 1, 0, 1, 1, 0], dtype=np.uint8)
+    got = resize_crop(u8.cuda(), boxes, P, flip).cpu()
+    src_f = u8.permute(0, 3, 1, 2).float() / 255.0
+    for b in range(B):
+        ref = _ref_resize(src_f[b], boxes[b], P, bool(flip[b]))
+        assert float((got[b] - ref).abs().max()) <= 2e-6, b
+    # float CHW source, no flip
+    fsrc = torch.rand(B, 3, H, W, generator=g)
+    got = resize_crop(fsrc.cuda(), boxes, P).cpu()
+    for b in range(B):
+        assert float((got[b] - _ref_resize(fsrc[b], boxes[b], P, False)).abs().max()) <= 2e-6, b
+    with pytest.raises(ValueError):
+        resize_crop(u8.cuda(), np.array([[0, 0, H + 1, W]] * B, dtype=np.int32), P)
+
+
+def test_colour_jitter_matches_torchvision_float_formulas():
+    from stil_tta_amd.augment import resize_crop
+    g = torch.Generator().manual_seed(2)
+    B, H, W, P = 4, 40, 48, 40
+    src = torch.rand(B, 3, H, W, generator=g)
+    boxes = np.array([[0, 0, H, W], [3, 4, 30, 30], [0, 8, 40, 40], [10, 0, 20, 48]], dtype=np.int32)
+    jit = np.array([[1.3, 0.6, 1.5, 0.0], [0.4, 1.7, 0.3, 1.0], [1.0, 1.0, 1.0, 0.0], [1.8, 0.2, 1.0, 0.0]], dtype=np.float32)
+    got = resize_crop(src.cuda(), boxes, P, None, jit).cpu()
+
+    def gray(x):
+        return (0.2989 * x[0] + 0.587 * x[1] + 0.114 * x[2]).unsqueeze(0)
+
+    for b in range(B):
+        br, ct, sa, gr = [float(v) for v in jit[b]]
+        mean = gray((src[b] * br).clamp(0, 1)).mean()          # adjust_contrast's constant: the jittered SOURCE image
+        x = _ref_resize(src[b], boxes[b], P, False)
+        x = (x * br).clamp(0, 1)
+        x = (ct * x + (1 - ct) * mean).clamp(0, 1)
+        x = (sa * x + (1 - sa) * gray(x)).clamp(0, 1)
+        if gr:
+            x = gray(x).expand(3, -1, -1)
+        assert float((got[b] - x).abs().max()) <= 5e-6, b
+    assert torch.equal(got[2], resize_crop(src.cuda(), boxes, P).cpu()[2])   # identity factors change nothing
+
+
+def test_batch_builder_feeds_the_training_step():
+    """ContrastiveBatchBuilder yields the reference's part tuple; a step on its output runs and is finite."""
+    from stil_tta_amd import STiLModel
+    from stil_tta_amd.augment import ContrastiveBatchBuilder
+    from stil_tta_amd.driver import train_step
+    from stil_tta_amd.flat import StilAdam
+    g = torch.Generator().manual_seed(4)
+    N, fl = 48, [3, 4] + [1] * 3
+    imgs = torch.randint(0, 256, (N, 80, 72, 3), generator=g, dtype=torch.uint8)
+    table = torch.cat([torch.randint(0, 3, (N, 1), generator=g).float(), torch.randint(0, 4, (N, 1), generator=g).float(), torch.randn(N, 3, generator=g)], 1)
+    labels = torch.randint(0, 5, (N,), generator=g)
+    lab = ContrastiveBatchBuilder(imgs[:8], table[:8], labels[:8], 64, "dvm", 0.3, 0.95, labelled=True)
+    unl = ContrastiveBatchBuilder(imgs[8:], table[8:], labels[8:], 64, "dvm", 0.3, 0.95, labelled=False)
+    bl, bu = lab(torch.tensor([0, 5])), unl(torch.randperm(40, generator=g)[:14])
+    im, tab, y, orig, ident = bu
+    assert im[1].shape == (14, 3, 64, 64) and orig.shape == (14, 3, 64, 64) and tab[0].shape == tab[1].shape == (14, 5)
+    assert y.dtype == torch.int64 and ident.dtype == torch.bool and not bool(ident.any()) and bool(bl[4].all())
+    assert float(im[1].min()) >= 0.0 and float(im[1].max()) <= 1.0
+    assert int((tab[0] != tab[1]).sum(1).max()) <= 1          # int(5 * 0.3) = 1 column per row
+    assert bool((tab[1][:, :2] == tab[1][:, :2].round()).all())  # categorical columns stay valid codes (marginal values)
+    torch.manual_seed(0)
+    m = STiLModel(dict(model="resnet18", embedding_dim=512, field_lengths=fl, num_classes=5, start_epoch=0, batch_size=16, th1=0.3, img_size=64))
+    m.setup_device("cuda"); m.train(); m.current_epoch = 1
+    m.prototypes.copy_(F.normalize(torch.randn(5, 128, generator=g)).cuda())
+    loss = train_step(m, StilAdam(m.flat, lr=1e-3), {"l": bl, "u": bu})
+    assert bool(torch.isfinite(loss))

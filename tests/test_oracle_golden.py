@@ -151,3 +151,18 @@ def test_cotraining_oracle_matches_reference_golden(name):
     for key in fx.files:
         if key.startswith("ssum_"):
             assert abs(float(sd[key[5:]].double().sum()) - float(fx[key])) <= 2e-5 * (1.0 + float(fx["sabs_" + key[5:]])), key
+
+
+def test_tab_corrupt_restatement_matches_reference_golden():
+    """datasets/ContrastiveImagingAndTabularDataset.py:146-158: the restated `corrupt` (draws made explicit) against the
+    outputs of the reference's own method under the same draws (tests/golden/tab_corrupt.npz, oracle/make_golden_data.py)."""
+    import numpy as np
+    from oracle.make_golden_data import corrupt_oracle
+    fx = np.load(os.path.join(GOLD, "tab_corrupt.npz"))
+    table = fx["table"]
+    for tag in ("c030", "c000", "c100", "c005"):
+        out, idx, pos = fx[tag + "_out"], fx[tag + "_idx"], fx[tag + "_pos"]
+        assert idx.shape[1] == int(table.shape[1] * int(tag[1:]) / 100)
+        for s in range(len(out)):
+            assert len(set(idx[s].tolist())) == idx.shape[1]        # random.sample: distinct columns
+            assert np.array_equal(corrupt_oracle(table[s % len(table)], table.T, idx[s], pos[s]), out[s])
