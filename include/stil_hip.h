@@ -55,8 +55,10 @@ int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, 
  * rows per output tile / tile variant stil_gemm_nt uses for an [M,N] output under `tune` (colstats granularity, bench bookkeeping) */
 int stil_gemm_nt_tile_rows(int M, int N, int tune);
 int stil_gemm_nt_variant(int M, int N, int tune);
-/* the instantiation stil_gemm_nt launches for these operands: variant + 100 * bk32 + 1000 * acc2 + 10000 * vec (16-byte loads) */
-int stil_gemm_nt_config(const float* A, const float* W, int M, int N, int K, int lda, int ldb, int srcC, int KH, int KW, int tune);
+/* the instantiation stil_gemm_nt launches for these operands: variant + 100 * bk32 + 1000 * acc2 + 10000 * vec (16-byte
+ * loads) + 100000 * plain (`plain` = 1: 1x1 / stride 1 / no padding / identity output map -- A is a plain row-major matrix
+ * and the kernel's geometry code is compiled out) */
+int stil_gemm_nt_config(const float* A, const float* W, int M, int N, int K, int lda, int ldb, int srcC, int KH, int KW, int plain, int tune);
 
 /* Weight gradient  dW (+)= dY[M,N]^T . Xgather[M,K]  (split over M, slab partials + ordered reduce).
  * KH*KW > 1: dW is written in the reference layout (N, srcC, KH, KW); else [N, Kdst] (first Kdst columns).

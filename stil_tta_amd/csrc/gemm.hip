@@ -82,7 +82,10 @@ __device__ __forceinline__ float4 ld4_sel(const float* p, const float* safe, boo
 // partial sums).  With ACC2 the MFMAs of FLUSH consecutive k-tiles (64 products) chain into a partial accumulator that
 // is then added to the master one: noise ~ (8 + sqrt(K/64)) eps, at the cost of 16 VGPRs per 32x32 tile and 16 v_add
 // per 32 MFMAs.  Used for K >= 512 (shorter reductions gain nothing).
-template <int TM, int TN, int BK, bool VEC, bool ACC2 = false>
+// PLAIN: the A operand is a plain row-major matrix (1x1 convolution with stride 1 / no padding, nn.Linear) and the output
+// map is the identity: the (n, oy, ox) row decode, the tap walk and the output re-map -- ~500 integer instructions per
+// workgroup, as many as the MFMAs of a K = 64 tile take -- are compiled out.
+template <int TM, int TN, int BK, bool VEC, bool ACC2 = false, bool PLAIN = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
   constexpr int BM = 64 * TM, BN = 64 * TN, LS = BK + 4;   // LS = 20 / 36: conflict-free ds_read_b128 (i*LS mod 64 distinct)
   constexpr int KQ = BK / 4, RP = 256 / KQ;                 // float4 per tile row, tile rows per load pass
@@ -103,11 +106,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
   for (int i = 0; i < RA; ++i) {
     int m = tm * BM + r0 + RP * i;
     a_ok[i] = m < p.M;
-    int mm = a_ok[i] ? m : 0;
-    int ohw = g.OH * g.OW;
-    int n = mm / ohw, rem = mm - n * ohw;
-    int oy = rem / g.OW;
-    a_n[i] = n; a_oy[i] = oy; a_ox[i] = rem - oy * g.OW;
+    if constexpr (PLAIN) {
+      a_n[i] = a_ok[i] ? m : 0; a_oy[i] = 0; a_ox[i] = 0;   // a_n doubles as the row index
+    } else {
+      int mm = a_ok[i] ? m : 0;
+      int ohw = g.OH * g.OW;
+      int n = mm / ohw, rem = mm - n * ohw;
+      int oy = rem / g.OW;
+      a_n[i] = n; a_oy[i] = oy; a_ox[i] = rem - oy * g.OW;
+    }
   }
   const float* b_ptr[RB];
   bool b_ok[RB];
@@ -124,6 +131,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
   const float* a_src[RA];
   bool a_val[RA];
   auto set_tap = [&](int tap) {
+    if constexpr (PLAIN) {
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        a_val[i] = a_ok[i];
+        a_src[i] = p.A + (long)a_n[i] * p.lda + kq * 4;
+      }
+      return;
+    }
     const int ky = tap / g.KW, kx = tap - ky * g.KW;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
@@ -144,7 +159,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
     }
   };
   int cur_tap = 0, c0 = 0, kb = 0;  // c0: channel offset inside the tap; kb = cur_tap*C + c0 (column of W)
-  const int ntaps = g.KH * g.KW;
+  const int ntaps = PLAIN ? 1 : g.KH * g.KW;
   set_tap(0);
   auto gload = [&]() {
     const int nval = g.C - (c0 + kq * 4);   // <= 0 only in the K tail of a plain GEMM (C == K, K % BK != 0)
@@ -187,7 +202,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
   const int nk = ntaps * ((g.C + BK - 1) / BK);
   // Interior fast path (block-uniform): single-tap gathers (plain GEMM, 1x1 conv) whose tile lies fully inside M x N
   // and whose K is a multiple of BK need no predicate at all -> unconditional 16-byte loads, pointer += BK.
-  const bool full = VEC && ntaps == 1 && g.mode == 0 && (g.C % BK == 0) && (tm + 1) * BM <= p.M && (tn + 1) * BN <= p.N;
+  const bool full = VEC && ntaps == 1 && (PLAIN || g.mode == 0) && (g.C % BK == 0) && (tm + 1) * BM <= p.M && (tn + 1) * BN <= p.N;
   auto mainloop = [&](auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
     auto load = [&]() {
@@ -345,7 +360,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
         const int row_m = tm * BM + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row_m >= p.M) continue;
         long row = row_m;
-        if (p.os != 1) {
+        if (!PLAIN && p.os != 1) {
           const int ohw = g.OH * g.OW;
           const int n = row_m / ohw, rem = row_m - n * ohw;
           const int oy = rem / g.OW, ox = rem - oy * g.OW;
@@ -563,8 +578,10 @@ static inline int is_vec(const void* p, int ld) { return (((uintptr_t)p) % 16 ==
 static bool g_nt_attr = false;
 static int gemm_nt_attr() {
   if (g_nt_attr) return STIL_OK;
-  hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<2, 2, 32, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_kernel<2, 2, 32, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<2, 2, 32, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_kernel<2, 2, 32, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_kernel<2, 2, 32, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_kernel<2, 2, 32, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   if (e != hipSuccess) { stil_set_error("gemm_nt: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return STIL_EHIP; }
   g_nt_attr = true;
   return STIL_OK;
@@ -587,15 +604,16 @@ extern "C" int stil_gemm_nt_variant(int M, int N, int tune) {
 // rows per output tile of the variant stil_gemm_nt picks for [M,N] (the granularity of `colstats`)
 extern "C" int stil_gemm_nt_tile_rows(int M, int N, int tune) { return stil_gemm_nt_variant(M, N, tune) == 11 ? 64 : 128; }
 
-// The kernel instantiation stil_gemm_nt launches for these operands, as variant + 100 * bk32 + 1000 * acc2 + 10000 * vec
-// (bench bookkeeping: names the rocprofv3 row of a launch).  The launcher below calls the same function.
+// The kernel instantiation stil_gemm_nt launches for these operands, as variant + 100 * bk32 + 1000 * acc2 + 10000 * vec +
+// 100000 * plain (bench bookkeeping: names the rocprofv3 row of a launch).  `plain`: 1x1 / stride 1 / no padding / identity
+// output map, i.e. A is a plain row-major matrix.  The launcher below calls the same function.
 extern "C" int stil_gemm_nt_config(const float* A, const float* W, int M, int N, int K, int lda, int ldb, int srcC, int KH, int KW,
-                                   int tune) {
+                                   int plain, int tune) {
   const int variant = stil_gemm_nt_variant(M, N, tune);
   const bool bk32 = (tune / 100) % 10 == 1 && (K % 32 == 0) && (KH * KW == 1 || srcC % 32 == 0);
   const bool acc2 = tune / 1000 == 2 || (tune / 1000 == 0 && K >= 512);
   const bool vec = is_vec(A, lda) && (srcC % 4 == 0) && is_vec(W, ldb) && (K % 4 == 0);  // every 16-byte load aligned and entirely in or out
-  return variant + 100 * ((vec && bk32) ? 1 : 0) + 1000 * (acc2 ? 1 : 0) + 10000 * (vec ? 1 : 0);
+  return variant + 100 * ((vec && bk32) ? 1 : 0) + 1000 * (acc2 ? 1 : 0) + 10000 * (vec ? 1 : 0) + 100000 * ((plain && KH * KW == 1) ? 1 : 0);
 }
 
 extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, int lda, int ldb, int ldc,
@@ -623,7 +641,9 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   int rc = check_geom(p.g, 0);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  const int cfg = stil_gemm_nt_config(A, W, M, N, K, lda, ldb, srcC, KH, KW, tune);
+  // plain row-major A and identity output map: the geometry code is compiled out (gemm_nt_kernel<..., PLAIN>)
+  const bool plain = KH * KW == 1 && stride == 1 && pad_y == 0 && pad_x == 0 && mode == 0 && p.os == 1 && srcH == OH && srcW == OW;
+  const int cfg = stil_gemm_nt_config(A, W, M, N, K, lda, ldb, srcC, KH, KW, plain ? 1 : 0, tune);
   const int variant = cfg % 100;
   const bool bk32 = (cfg / 100) % 10 == 1;   // BK = 32 halves the barriers per MFMA; needs whole taps and vector loads
   const bool acc2 = (cfg / 1000) % 10 == 1;  // long reductions: two-level accumulation (see gemm_nt_kernel)
@@ -634,8 +654,10 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   do {                                                                                                        \
     const dim3 grid_(cdiv(M, 64 * TM_) * cdiv(N, 64 * TN_));                                                  \
     const size_t lds_ = (size_t)2 * 64 * (TM_ + TN_) * (BK_ + 4) * sizeof(float);                             \
-    if (acc2) hipLaunchKernelGGL((gemm_nt_kernel<TM_, TN_, BK_, V_, true>), grid_, dim3(256), lds_, s, p);    \
-    else hipLaunchKernelGGL((gemm_nt_kernel<TM_, TN_, BK_, V_, false>), grid_, dim3(256), lds_, s, p);        \
+    if (acc2 && plain) hipLaunchKernelGGL((gemm_nt_kernel<TM_, TN_, BK_, V_, true, true>), grid_, dim3(256), lds_, s, p);   \
+    else if (acc2) hipLaunchKernelGGL((gemm_nt_kernel<TM_, TN_, BK_, V_, true, false>), grid_, dim3(256), lds_, s, p);      \
+    else if (plain) hipLaunchKernelGGL((gemm_nt_kernel<TM_, TN_, BK_, V_, false, true>), grid_, dim3(256), lds_, s, p);     \
+    else hipLaunchKernelGGL((gemm_nt_kernel<TM_, TN_, BK_, V_, false, false>), grid_, dim3(256), lds_, s, p);               \
   } while (0)
   if (!vec) {  // unaligned / ragged operands (K = 286 classifier gradients ...): scalar guarded loads
     if (variant == 11) LAUNCH_NT(1, 1, 16, false); else if (variant == 21) LAUNCH_NT(2, 1, 16, false); else LAUNCH_NT(2, 2, 16, false);

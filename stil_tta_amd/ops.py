@@ -158,7 +158,9 @@ def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None,
         s2 = geom[7] * geom[7] if geom[9] == 1 else 1
         src = (M // (geom[3] * geom[4])) * geom[0] * geom[1] * geom[2]  # gather source (each element fetched once, ideally)
         nbytes = 4.0 * (src + N * K + M * N * (1 + (resid is not None) + (pre is not None)))
-        cfg = L.gemm_nt_config(_p(A), _p(W), M, N, K, lda, ldb, geom[2], geom[5], geom[6], TUNE["gemm"])
+        plain = int(geom[5] * geom[6] == 1 and geom[7] == 1 and pads == (0, 0) and geom[9] == 0 and outmap[0] == 1
+                    and geom[0] == geom[3] and geom[1] == geom[4])
+        cfg = L.gemm_nt_config(_p(A), _p(W), M, N, K, lda, ldb, geom[2], geom[5], geom[6], plain, TUNE["gemm"])
         meta = (cfg, 2.0 * M * N * K / s2, (M, N, K, geom[5], geom[7], geom[9]), nbytes)
     L.gemm_nt(_p(A), _p(W), _p(out), M, N, K, lda, ldb, ldc, *geom[:8], pads[0], pads[1], geom[9], *outmap,
               _p(bias), _p(sub), _p(scale), _p(shift), _p(resid),

@@ -33,11 +33,11 @@ def run_nt(shape):
     ms = s0.elapsed_time(e0) / rounds
     return ms, 2.0 * M * N * K / ms / 1e9
 
-NT += [(50176, 256, 1024, 1, 1, 0, 14), (12544, 512, 2048, 1, 1, 0, 7), (12544, 2048, 512, 1, 1, 0, 7), (50176, 1024, 256, 1, 1, 0, 14)]
+NT += [(50176, 256, 1024, 1, 1, 0, 14), (12544, 512, 2048, 1, 1, 0, 7), (12544, 2048, 512, 1, 1, 0, 7), (802816, 64, 64, 1, 1, 0, 56), (802816, 256, 128, 1, 1, 0, 56)]
 def tune(v):
     return lambda: ops.TUNE.__setitem__("gemm", v)
 # tune = variant + 100 * bk32 + 1000 * acc2 (include/stil_hip.h): auto / single-chain accumulation / per tile variant
-variants = [("auto", tune(0)), ("auto-1chain", tune(1000)), ("v11", tune(11)), ("v11-1chain", tune(1011)), ("v21", tune(21)), ("v21-1chain", tune(1021)), ("v22", tune(22))]
+variants = [("auto", tune(0)), ("auto-1chain", tune(1000)), ("v11", tune(11)), ("v21", tune(21)), ("v22", tune(22))]
 res = {}
 for r in range(2):  # interleaved rounds
     for name, setter in variants:
