@@ -258,6 +258,240 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
   }
 }
 
+// ---------------------------------------------------------------- MFMA attention (v_mfma_f32_16x16x4_f32, exact fp32)
+// Same contract as attn_fwd_kernel / attn_bwd_kernel (one workgroup per (batch, head)); the six matrix products run on
+// the matrix pipe as 16x16 output tiles (sequence lengths are padded to multiples of 16 with zero rows, so S = 65 costs
+// 80, not 96 or 128), every operand is read from LDS once per MFMA instead of once per FMA.  fp32 MFMA has the VALU's
+// FLOP rate: the gain is LDS traffic and instruction count (the VALU kernels run at ~10 % of the FMA rate).
+// Operand maps of 16x16x4: A[row = l & 15][k = l >> 4], B[k = l >> 4][col = l & 15], C/D[col = l & 15][row = 4 (l >> 4) + r].
+// LDS row strides are == 20 (mod 32) floats: a matrix read "row = l & 15, k = l >> 4" is then conflict-free
+// (s i mod 64 takes 16 distinct multiples of 4 for s = 4 * odd), and the transposed reads (row = l >> 4, column = l & 15)
+// that the backward needs for dS^T / Pd^T / the B operands overlap on at most 12 of 64 banks.  The operands the LATER
+// phases need (V in forward; K and Q in backward) are fetched into registers at kernel start, so only one global-memory
+// latency is exposed per workgroup.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__host__ __device__ static inline int attn_pad(int n) { return ((n + 4 - 20 + 31) / 32) * 32 + 20; }   // smallest s >= n + 4 with s == 20 (mod 32)
+__host__ __device__ static inline int attn_up16(int n) { return (n + 15) & ~15; }
+
+// rows [r0, r1) of a [*, d] matrix with row stride ld (floats) -> LDS rows of stride dp; rows >= nvalid are zero-filled
+__device__ __forceinline__ void attn_stage(float* dst, int dp, const float* src, long ld, int nvalid, int nrows, int d4) {
+  for (int i = threadIdx.x; i < nrows * d4; i += 256) {
+    const int r = i / d4, c = i - r * d4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < nvalid) v = *reinterpret_cast<const float4*>(src + (long)r * ld + c * 4);
+    *reinterpret_cast<float4*>(dst + r * dp + c * 4) = v;
+  }
+}
+
+// The k loops run 4 MFMA steps (16 k) per iteration with the 8 operand reads issued first: K is a multiple of 16.
+// acc += X[ti*16 .. +16, :K] . Y[tj*16 .. +16, :K]^T   (both row-major in LDS: "NT" product, e.g. Q K^T, dO V^T)
+__device__ __forceinline__ f32x4 attn_tile_nt(const float* X, int sx, const float* Y, int sy, int ti, int tj, int K, int lane) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* a = X + (ti * 16 + (lane & 15)) * sx + (lane >> 4);
+  const float* b = Y + (tj * 16 + (lane & 15)) * sy + (lane >> 4);
+  for (int k = 0; k < K; k += 16) {
+    float av[4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { av[u] = a[k + 4 * u]; bv[u] = b[k + 4 * u]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+  }
+  return acc;
+}
+// acc += X[ti*16 .. +16, :K] . Y[:K, tc*16 .. +16]        ("NN": P V, dS K)
+__device__ __forceinline__ f32x4 attn_tile_nn(const float* X, int sx, const float* Y, int sy, int ti, int tc, int K, int lane) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* a = X + (ti * 16 + (lane & 15)) * sx + (lane >> 4);
+  const float* b = Y + (lane >> 4) * sy + tc * 16 + (lane & 15);
+  for (int k = 0; k < K; k += 16) {
+    float av[4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { av[u] = a[k + 4 * u]; bv[u] = b[(k + 4 * u) * sy]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+  }
+  return acc;
+}
+// acc += X[:K, tj*16 .. +16]^T . Y[:K, tc*16 .. +16]      ("TN": Pd^T dO, dS^T Q)
+__device__ __forceinline__ f32x4 attn_tile_tn(const float* X, int sx, const float* Y, int sy, int tj, int tc, int K, int lane) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* a = X + (lane >> 4) * sx + tj * 16 + (lane & 15);
+  const float* b = Y + (lane >> 4) * sy + tc * 16 + (lane & 15);
+  for (int k = 0; k < K; k += 16) {
+    float av[4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { av[u] = a[(k + 4 * u) * sx]; bv[u] = b[(k + 4 * u) * sy]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// register prefetch of a [nvalid, d] matrix (row stride ld) for a later attn_unstage into LDS: NPF float4 per thread
+// cover nrows * d / 4 <= 256 * NPF elements (the launcher checks); rows >= nvalid read as zero
+template <int NPF>
+__device__ __forceinline__ void attn_prefetch(float4 (&r)[NPF], const float* src, long ld, int nvalid, int nrows, int d4) {
+#pragma unroll
+  for (int u = 0; u < NPF; ++u) {
+    const int i = threadIdx.x + 256 * u;
+    const int row = i / d4, c = i - row * d4;
+    r[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < nrows * d4 && row < nvalid) r[u] = *reinterpret_cast<const float4*>(src + (long)row * ld + c * 4);
+  }
+}
+template <int NPF>
+__device__ __forceinline__ void attn_unstage(float* dst, int dp, const float4 (&r)[NPF], int nrows, int d4) {
+#pragma unroll
+  for (int u = 0; u < NPF; ++u) {
+    const int i = threadIdx.x + 256 * u;
+    const int row = i / d4, c = i - row * d4;
+    if (i < nrows * d4) *reinterpret_cast<float4*>(dst + row * dp + c * 4) = r[u];
+  }
+}
+constexpr int ATTN_NPF = 16;   // up to 128 rows x 128 floats (or 256 x 64) per prefetched matrix
+
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];
+  const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+  const int d = p.d, d4 = d >> 2, Sq = p.Sq, Skv = p.Skv, SqP = attn_up16(Sq), SkP = attn_up16(Skv);
+  const int dq = d + 4, dp = attn_pad(d), sp = attn_pad(SkP);   // Q, K: read "row = l & 15" only -> stride d + 4 (== 4 mod 64) is conflict-free
+  float* Qs = sh;                  // [SqP][dq]
+  float* KV = Qs + SqP * dq;       // K as [SkP][dq], then V as [SkP][dp]
+  float* Ps = KV + SkP * dp;       // [SqP][sp]
+  const long ld = 3L * p.H * d;
+  const float* base = p.qkv + (long)b * p.T * ld + h * d;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  float4 vreg[ATTN_NPF];
+  attn_stage(Qs, dq, base + (long)p.q_off * ld, ld, Sq, SqP, d4);
+  attn_stage(KV, dq, base + (long)p.kv_off * ld + p.H * d, ld, Skv, SkP, d4);
+  attn_prefetch<ATTN_NPF>(vreg, base + (long)p.kv_off * ld + 2 * p.H * d, ld, Skv, SkP, d4);   // V: in flight under Q K^T
+  __syncthreads();
+  const int ntq = SqP >> 4, ntk = SkP >> 4, ntc = d >> 4;
+  for (int t = w; t < ntq * ntk; t += 4) {                       // S = scale * Q K^T
+    const int ti = t / ntk, tj = t - ti * ntk;
+    const f32x4 acc = attn_tile_nt(Qs, dq, KV, dq, ti, tj, d, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ps[(ti * 16 + (lane >> 4) * 4 + r) * sp + tj * 16 + (lane & 15)] = acc[r] * p.scale;
+  }
+  __syncthreads();
+  attn_unstage<ATTN_NPF>(KV, dp, vreg, SkP, d4);                 // V overwrites K
+  float* pg = p.probs + ((long)(b * p.H + h) * Sq) * Skv;
+  const unsigned char* mk = p.mask ? p.mask + ((long)(b * p.H + h) * Sq) * Skv : nullptr;
+  for (int i = w; i < Sq; i += 4) {                              // softmax over the valid columns; padding stays 0
+    float* pr = Ps + i * sp;
+    float m = -INFINITY;
+    for (int j = lane; j < Skv; j += 64) m = fmaxf(m, pr[j]);
+    m = wave_max(m);
+    float sacc = 0.f;
+    for (int j = lane; j < Skv; j += 64) { float e = expf(pr[j] - m); pr[j] = e; sacc += e; }
+    sacc = wave_sum(sacc);
+    const float inv = 1.f / sacc;
+    for (int j = lane; j < Skv; j += 64) {
+      float pv = pr[j] * inv;
+      pg[(long)i * Skv + j] = pv;
+      if (mk) pv = mk[(long)i * Skv + j] ? pv * p.drop_scale : 0.f;
+      pr[j] = pv;
+    }
+  }
+  __syncthreads();
+  float* ob = p.out + ((long)b * p.T + p.q_off) * (p.H * d) + h * d;
+  for (int t = w; t < ntq * ntc; t += 4) {                       // O = P V
+    const int ti = t / ntc, tc = t - ti * ntc;
+    const f32x4 acc = attn_tile_nn(Ps, sp, KV, dp, ti, tc, SkP, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = ti * 16 + (lane >> 4) * 4 + r;
+      if (i < Sq) ob[(long)i * (p.H * d) + tc * 16 + (lane & 15)] = acc[r];
+    }
+  }
+}
+
+// stride for matrices that are only read "row = l >> 4, column = l & 15" (B operands K, Q of the last phase): == 16 (mod 64)
+__host__ __device__ static inline int attn_padT(int d) { return ((d - 16 + 63) / 64) * 64 + 16; }
+
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];
+  const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+  const int d = p.d, d4 = d >> 2, Sq = p.Sq, Skv = p.Skv, SqP = attn_up16(Sq), SkP = attn_up16(Skv);
+  const int dq = d + 4, dp = attn_pad(d), dt = attn_padT(d), sp = attn_pad(SkP);
+  float* R0 = sh;                  // dO as [SqP][dp], later Q as [SqP][dt]
+  float* R1 = R0 + SqP * dp;       // V as [SkP][dq], later K as [SkP][dt]
+  float* X = R1 + SkP * dt;        // [SqP][sp]: dropped probabilities Pd, later dP -> dS (time-shared: one tile matrix, not two)
+  const long ld = 3L * p.H * d;
+  const float* base = p.qkv + (long)b * p.T * ld + h * d;
+  float* dbase = p.dqkv + (long)b * p.T * ld + h * d;
+  const float* dob = p.dout + ((long)b * p.T + p.q_off) * (p.H * d) + h * d;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const float* pg = p.probs + ((long)(b * p.H + h) * Sq) * Skv;
+  const unsigned char* mk = p.mask ? p.mask + ((long)(b * p.H + h) * Sq) * Skv : nullptr;
+  const int ntq = SqP >> 4, ntk = SkP >> 4, ntc = d >> 4;
+  float4 kreg[ATTN_NPF], qreg[ATTN_NPF];
+  attn_stage(R0, dp, dob, (long)p.H * d, Sq, SqP, d4);
+  attn_stage(R1, dq, base + (long)p.kv_off * ld + 2 * p.H * d, ld, Skv, SkP, d4);
+  for (int e = tid; e < SqP * SkP; e += 256) {                   // Pd = P * keep (zero in the padding)
+    const int i = e / SkP, j = e - i * SkP;
+    float v = 0.f;
+    if (i < Sq && j < Skv) {
+      const long g = (long)i * Skv + j;
+      v = pg[g] * (mk ? (mk[g] ? p.drop_scale : 0.f) : 1.f);
+    }
+    X[i * sp + j] = v;
+  }
+  attn_prefetch<ATTN_NPF>(kreg, base + (long)p.kv_off * ld + p.H * d, ld, Skv, SkP, d4);   // K, Q: needed only by the last phase
+  attn_prefetch<ATTN_NPF>(qreg, base + (long)p.q_off * ld, ld, Sq, SqP, d4);
+  __syncthreads();
+  for (int t = w; t < ntk * ntc; t += 4) {                       // dV += Pd^T dO
+    const int tj = t / ntc, tc = t - tj * ntc;
+    const f32x4 acc = attn_tile_tn(X, sp, R0, dp, tj, tc, SqP, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = tj * 16 + (lane >> 4) * 4 + r;
+      if (j < Skv) dbase[(long)(p.kv_off + j) * ld + 2 * p.H * d + tc * 16 + (lane & 15)] += acc[r];
+    }
+  }
+  __syncthreads();                                               // Pd is dead: X is free for dP
+  for (int t = w; t < ntq * ntk; t += 4) {                       // dP = (dO V^T) * keep
+    const int ti = t / ntk, tj = t - ti * ntk;
+    const f32x4 acc = attn_tile_nt(R0, dp, R1, dq, ti, tj, d, lane);
+    const int j = tj * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = ti * 16 + (lane >> 4) * 4 + r;
+      float dpv = 0.f;
+      if (i < Sq && j < Skv) dpv = acc[r] * (mk ? (mk[(long)i * Skv + j] ? p.drop_scale : 0.f) : 1.f);
+      X[i * sp + j] = dpv;
+    }
+  }
+  __syncthreads();                                               // dO and V are dead: R0 / R1 take Q / K
+  attn_unstage<ATTN_NPF>(R1, dt, kreg, SkP, d4);
+  attn_unstage<ATTN_NPF>(R0, dt, qreg, SqP, d4);
+  for (int i = w; i < Sq; i += 4) {                              // dS = P * (dP - rowsum(dP * P)) * scale
+    float sacc = 0.f;
+    for (int j = lane; j < Skv; j += 64) sacc += X[i * sp + j] * pg[(long)i * Skv + j];
+    sacc = wave_sum(sacc);
+    for (int j = lane; j < Skv; j += 64) X[i * sp + j] = pg[(long)i * Skv + j] * (X[i * sp + j] - sacc) * p.scale;
+  }
+  __syncthreads();
+  for (int t = w; t < ntq * ntc; t += 4) {                       // dQ += dS K
+    const int ti = t / ntc, tc = t - ti * ntc;
+    const f32x4 acc = attn_tile_nn(X, sp, R1, dt, ti, tc, SkP, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = ti * 16 + (lane >> 4) * 4 + r;
+      if (i < Sq) dbase[(long)(p.q_off + i) * ld + tc * 16 + (lane & 15)] += acc[r];
+    }
+  }
+  for (int t = w; t < ntk * ntc; t += 4) {                       // dK += dS^T Q   (other slot of dqkv than dQ: no hazard)
+    const int tj = t / ntc, tc = t - tj * ntc;
+    const f32x4 acc = attn_tile_tn(X, sp, R0, dt, tj, tc, SqP, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = tj * 16 + (lane >> 4) * 4 + r;
+      if (j < Skv) dbase[(long)(p.kv_off + j) * ld + p.H * d + tc * 16 + (lane & 15)] += acc[r];
+    }
+  }
+}
+
 // ---------------------------------------------------------------- elementwise
 // kind 1: dx = dy * (ref > 0)   (ref = relu output) ; kind 2: dx = dy * gelu'(ref)  (ref = pre-activation)
 __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ ref, float* __restrict__ dx,
@@ -490,11 +724,25 @@ static int attn_check(int T, int H, int d, int q_off, int Sq, int kv_off, int Sk
   (void)H;
   return STIL_OK;
 }
+// LDS of the MFMA kernels (padded tiles) and their eligibility: head dim a multiple of 16, everything in 160 KiB
+static size_t attn_mfma_lds(int Sq, int Skv, int d, bool bwd) {
+  const int SqP = attn_up16(Sq), SkP = attn_up16(Skv), dp = attn_pad(d), sp = attn_pad(SkP);
+  const size_t fl = bwd ? (size_t)SqP * dp + (size_t)SkP * attn_padT(d) + (size_t)SqP * sp     // dO/Q, V/K, Pd -> dP -> dS
+                        : (size_t)SqP * (d + 4) + (size_t)SkP * dp + (size_t)SqP * sp;        // Q, K/V, P
+  return fl * sizeof(float);
+}
+static bool attn_mfma_ok(int Sq, int Skv, int d, size_t lds) {
+  const int big = attn_up16(Sq > Skv ? Sq : Skv);
+  return d % 16 == 0 && d >= 16 && lds <= 160 * 1024 && Sq > 0 && Skv > 0 && (long)big * (d / 4) <= 256L * ATTN_NPF;
+}
+
 static bool g_attn_attr_set = false;
 static int attn_set_attr() {
   if (g_attn_attr_set) return STIL_OK;
   hipError_t e1 = hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipError_t e2 = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e1 != hipSuccess || e2 != hipSuccess) {
     stil_set_error("attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     return STIL_EHIP;
@@ -510,13 +758,17 @@ extern "C" int stil_attention_fwd(const float* qkv, float* out, float* probs, co
   int rc = attn_check(T, H, d, q_off, Sq, kv_off, Skv);
   if (rc) return rc;
   size_t lds = ((size_t)Sq * d + (size_t)Skv * (d + 4) + (size_t)Sq * Skv) * sizeof(float);
-  STIL_REQUIRE(lds <= 160 * 1024, "stil_attention_fwd: needs %zu B of LDS (> 160 KiB): Sq=%d Skv=%d d=%d", lds, Sq, Skv, d);
+  const size_t lds_m = attn_mfma_lds(Sq, Skv, d, false);   // MFMA path: d % 16 == 0 and its padded tiles fit
+  // matrix-pipe kernel unless it would keep fewer workgroups resident than the VALU kernel (both are latency-bound)
+  const bool mfma = attn_mfma_ok(Sq, Skv, d, lds_m) && (lds > 160 * 1024 || (160 * 1024) / lds_m >= (160 * 1024) / lds);
+  STIL_REQUIRE(mfma || lds <= 160 * 1024, "stil_attention_fwd: needs %zu B of LDS (> 160 KiB): Sq=%d Skv=%d d=%d", lds, Sq, Skv, d);
   if ((rc = attn_set_attr())) return rc;
   AttnArgs p;
   p.qkv = qkv; p.out = out; p.probs = probs; p.mask = mask; p.dout = nullptr; p.dqkv = nullptr;
   p.B = B; p.T = T; p.H = H; p.d = d; p.q_off = q_off; p.Sq = Sq; p.kv_off = kv_off; p.Skv = Skv;
   p.scale = scale; p.drop_scale = mask ? 1.f / (1.f - drop_p) : 1.f;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, p);
+  if (mfma) hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(B * H), dim3(256), lds_m, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, p);
   STIL_LAUNCH_CHECK();
   return STIL_OK;
 }
@@ -529,13 +781,17 @@ extern "C" int stil_attention_bwd(const float* dout, const float* qkv, const flo
   if (rc) return rc;
   int Smax = Sq > Skv ? Sq : Skv;
   size_t lds = ((size_t)2 * Smax * (d + 4) + (size_t)2 * Sq * Skv) * sizeof(float);
-  STIL_REQUIRE(lds <= 160 * 1024, "stil_attention_bwd: needs %zu B of LDS (> 160 KiB)", lds);
+  const size_t lds_m = attn_mfma_lds(Sq, Skv, d, true);
+  // matrix-pipe kernel unless it would keep fewer workgroups resident than the VALU kernel (both are latency-bound)
+  const bool mfma = attn_mfma_ok(Sq, Skv, d, lds_m) && (lds > 160 * 1024 || (160 * 1024) / lds_m >= (160 * 1024) / lds);
+  STIL_REQUIRE(mfma || lds <= 160 * 1024, "stil_attention_bwd: needs %zu B of LDS (> 160 KiB)", lds);
   if ((rc = attn_set_attr())) return rc;
   AttnArgs p;
   p.qkv = qkv; p.out = nullptr; p.probs = const_cast<float*>(probs); p.mask = mask; p.dout = dout; p.dqkv = dqkv;
   p.B = B; p.T = T; p.H = H; p.d = d; p.q_off = q_off; p.Sq = Sq; p.kv_off = kv_off; p.Skv = Skv;
   p.scale = scale; p.drop_scale = mask ? 1.f / (1.f - drop_p) : 1.f;
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, p);
+  if (mfma) hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(B * H), dim3(256), lds_m, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, p);
   STIL_LAUNCH_CHECK();
   return STIL_OK;
 }

@@ -214,8 +214,12 @@ def _ref_attn(qkv, H, win, mask, p):
 @pytest.mark.parametrize("B,T,H,d,wins,use_mask", [
     (3, 18, 8, 64, [(0, 18, 0, 18)], False), (2, 65, 8, 64, [(0, 65, 0, 65)], False),
     (2, 12, 4, 128, [(1, 4, 1, 4), (5, 7, 5, 7), (0, 1, 0, 12)], True), (2, 114, 4, 128, [(1, 49, 1, 49), (50, 64, 50, 64), (0, 1, 0, 114)], True),
-    (2, 9, 4, 16, [(0, 9, 0, 9)], False)])
+    (2, 9, 4, 16, [(0, 9, 0, 9)], False),
+    (2, 10, 2, 12, [(0, 10, 0, 10)], True),          # head dim not a multiple of 16: the VALU kernels
+    (2, 96, 2, 64, [(0, 96, 0, 96)], True)])         # a 6 x 6 tile grid of the MFMA kernels
 def test_attention(ops, B, T, H, d, wins, use_mask):
+    """softmax(q k^T) (dropout) v, forward and backward (models/Transformer.py:63-88, disentangle_transformer.py:49-94).
+    Head dims that are multiples of 16 run on the matrix pipe (attn_*_mfma_kernel, v_mfma_f32_16x16x4_f32)."""
     g = torch.Generator().manual_seed(T)
     qkv = torch.randn(B, T, 3 * H * d, generator=g, requires_grad=True)
     masks = [(torch.rand(B, H, w[1], w[3], generator=g) >= 0.1) for w in wins] if use_mask else None
