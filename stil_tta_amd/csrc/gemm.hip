@@ -77,6 +77,100 @@ __device__ __forceinline__ float4 ld4_sel(const float* p, const float* safe, boo
   return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// Epilogue shared by the tile kernels: optional per-tile column statistics of the raw product (training BatchNorm without
+// a statistics pass), then alpha / eval-BN affine / bias / residual / activation and the (optionally re-mapped) store.
+// acc: this wave's TM x TN 32x32 accumulators of output tile (tm, tn); red: >= 2 * 64 * TN floats of LDS scratch.
+template <int TM, int TN, bool PLAIN>
+__device__ __forceinline__ void gemm_nt_epilogue(const GemmNTArgs& p, f32x16 (&acc)[TM][TN], float* red, int tm, int tn, int wm, int wn,
+                                                 int li, int lh) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  const ConvGeom& g = p.g;
+  // per-tile column mean / M2 (Welford partials, combined in fixed order by bn_stats_final_tiles_kernel)
+  if (p.colstats) {
+    // red: [2 (wm)][BN] floats of LDS scratch that no other wave is still reading
+    const int rows_valid = min(BM, p.M - tm * BM);
+    float mean_t[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row_m = tm * BM + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (row_m < p.M) sacc += acc[i][j][r] * p.alpha;
+        }
+      sacc += __shfl_xor(sacc, 32, 64);
+      if (lh == 0) red[wm * BN + wn * TN * 32 + j * 32 + li] = sacc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int cs = wn * TN * 32 + j * 32 + li;
+      mean_t[j] = (red[cs] + red[BN + cs]) / (float)rows_valid;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row_m = tm * BM + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const float d = acc[i][j][r] * p.alpha - mean_t[j];
+          if (row_m < p.M) q += d * d;
+        }
+      q += __shfl_xor(q, 32, 64);
+      if (lh == 0) red[wm * BN + wn * TN * 32 + j * 32 + li] = q;
+    }
+    __syncthreads();
+    if (wm == 0 && lh == 0) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int cs = wn * TN * 32 + j * 32 + li, col = tn * BN + cs;
+        if (col < p.N) {
+          p.colstats[((long)tm * 2) * p.N + col] = mean_t[j];
+          p.colstats[((long)tm * 2 + 1) * p.N + col] = red[cs] + red[BN + cs];
+        }
+      }
+    }
+  }
+
+  // epilogue: C/D map of 32x32 tiles: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = tn * BN + wn * TN * 32 + j * 32 + li;
+    if (col >= p.N) continue;
+    const float bia = p.bias ? p.bias[col] : 0.f;
+    const float sb = p.sub ? p.sub[col] : 0.f;
+    const float sc = p.scale ? p.scale[col] : 1.f;
+    const float sh = p.shift ? p.shift[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row_m = tm * BM + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row_m >= p.M) continue;
+        long row = row_m;
+        if (!PLAIN && p.os != 1) {
+          const int ohw = g.OH * g.OW;
+          const int n = row_m / ohw, rem = row_m - n * ohw;
+          const int oy = rem / g.OW, ox = rem - oy * g.OW;
+          row = ((long)n * p.oOH + oy * p.os + p.opy) * p.oOW + ox * p.os + p.opx;
+        }
+        float v = acc[i][j][r] * p.alpha;
+        v = (v - sb) * sc + sh + bia;
+        if (p.resid) v += p.resid[row * p.ldr + col];
+        if (p.pre) p.pre[row * p.ldc + col] = v;
+        if (p.act == 1) v = fmaxf(v, 0.f);
+        else if (p.act == 2) v = gelu_f(v);
+        p.C[row * p.ldc + col] = v;
+      }
+    }
+  }
+}
+
 // ACC2: two-level accumulation.  v_mfma_f32_32x32x2_f32 is an exact fp32 fmaf chain, so a K-long reduction done in ONE
 // accumulator carries ~sqrt(K) eps of rounding noise -- measured 5x ATen-CPU's error at K = 4608 (oneDNN keeps many
 // partial sums).  With ACC2 the MFMAs of FLUSH consecutive k-tiles (64 products) chain into a partial accumulator that
@@ -292,90 +386,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
   };
   if (full) mainloop(std::true_type{}); else mainloop(std::false_type{});
 
-  // per-tile column mean / M2 (Welford partials, combined in fixed order by bn_stats_final_tiles_kernel)
-  if (p.colstats) {
-    float* red = lds;   // [2 (wm)][BN]; the main loop's last barrier has retired every LDS read
-    const int rows_valid = min(BM, p.M - tm * BM);
-    float mean_t[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      float sacc = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row_m = tm * BM + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (row_m < p.M) sacc += acc[i][j][r] * p.alpha;
-        }
-      sacc += __shfl_xor(sacc, 32, 64);
-      if (lh == 0) red[wm * BN + wn * TN * 32 + j * 32 + li] = sacc;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int cs = wn * TN * 32 + j * 32 + li;
-      mean_t[j] = (red[cs] + red[BN + cs]) / (float)rows_valid;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      float q = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row_m = tm * BM + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const float d = acc[i][j][r] * p.alpha - mean_t[j];
-          if (row_m < p.M) q += d * d;
-        }
-      q += __shfl_xor(q, 32, 64);
-      if (lh == 0) red[wm * BN + wn * TN * 32 + j * 32 + li] = q;
-    }
-    __syncthreads();
-    if (wm == 0 && lh == 0) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int cs = wn * TN * 32 + j * 32 + li, col = tn * BN + cs;
-        if (col < p.N) {
-          p.colstats[((long)tm * 2) * p.N + col] = mean_t[j];
-          p.colstats[((long)tm * 2 + 1) * p.N + col] = red[cs] + red[BN + cs];
-        }
-      }
-    }
-  }
-
-  // epilogue: C/D map of 32x32 tiles: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = tn * BN + wn * TN * 32 + j * 32 + li;
-    if (col >= p.N) continue;
-    const float bia = p.bias ? p.bias[col] : 0.f;
-    const float sb = p.sub ? p.sub[col] : 0.f;
-    const float sc = p.scale ? p.scale[col] : 1.f;
-    const float sh = p.shift ? p.shift[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row_m = tm * BM + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row_m >= p.M) continue;
-        long row = row_m;
-        if (!PLAIN && p.os != 1) {
-          const int ohw = g.OH * g.OW;
-          const int n = row_m / ohw, rem = row_m - n * ohw;
-          const int oy = rem / g.OW, ox = rem - oy * g.OW;
-          row = ((long)n * p.oOH + oy * p.os + p.opy) * p.oOW + ox * p.os + p.opx;
-        }
-        float v = acc[i][j][r] * p.alpha;
-        v = (v - sb) * sc + sh + bia;
-        if (p.resid) v += p.resid[row * p.ldr + col];
-        if (p.pre) p.pre[row * p.ldc + col] = v;
-        if (p.act == 1) v = fmaxf(v, 0.f);
-        else if (p.act == 2) v = gelu_f(v);
-        p.C[row * p.ldc + col] = v;
-      }
-    }
-  }
+  gemm_nt_epilogue<TM, TN, PLAIN>(p, acc, lds, tm, tn, wm, wn, li, lh);
 }
 
 // ---------------------------------------------------------------------------------------
