@@ -253,10 +253,15 @@ int stil_tab_corrupt_draw(int* idx, int* pos, int B, int n_cols, int n_rows, int
  *   optional horizontal flip -> optional colour (jitter[b] = brightness, contrast, saturation, gray flag; torchvision's
  *   float formulas in that order) -> * scale -> clip [0,1] -> float CHW [B,3,P,P].  Source: uint8 HWC [B,H,W,3] or float
  *   CHW [B,3,H,W] (exactly one non-null).  Replaces RandomResizedCrop / Resize / HorizontalFlip / ColorJitter / ToGray /
- *   convert_to_ts of utils/utils.py:33-59 and ContrastiveImagingAndTabularDataset.py:177-198 (GaussianBlur is not built).
+ *   convert_to_ts of utils/utils.py:33-59 and ContrastiveImagingAndTabularDataset.py:177-198 (GaussianBlur: stil_aug_blur).
  * stil_aug_gray_mean: per-sample mean grey level of the brightness-adjusted source image (what adjust_contrast blends with). */
 int stil_aug_gray_mean(const unsigned char* src_u8, const float* src_f32, const float* jitter, float* gmean, int B, int H,
                        int W, float scale, void* stream);
+/* stil_aug_blur: separable Gaussian blur of the whole source image (transforms.GaussianBlur(kernel_size, sigma), utils/utils.py:52):
+ *   torchvision's kernel weights, "reflect" borders; sigma[b] <= 0 copies sample b; -> float CHW [B,3,H,W] scaled by `scale`
+ *   (tmp: same size, the row-pass intermediate). */
+int stil_aug_blur(const unsigned char* src_u8, const float* src_f32, const float* sigma, float* tmp, float* out, int B, int H,
+                  int W, int ksize, float scale, void* stream);
 int stil_aug_resize(const unsigned char* src_u8, const float* src_f32, const int* box, const unsigned char* flip,
                     const float* jitter, const float* gmean, float* out, int B, int H, int W, int P, float scale,
                     void* stream);

@@ -512,5 +512,59 @@ def main():
               f"params_without_grad={n_none}  -> {os.path.relpath(path, ROOT)} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+def adam_layout(name="dvm_r18_noeman"):
+    """What the REFERENCE's configure_optimizers (STiLModel.py:557-577) builds: torch.optim.Adam over six parameter groups.
+    Its state_dict() after one step -- group sizes, group hyper-parameters, the shape of every parameter in id order,
+    which ids hold state -- is the `optimizer_states[0]` entry of a Lightning checkpoint; stored as
+    tests/golden/adam_layout.npz so that fit.adam_state_dict can be held to it."""
+    hp, sd, batch, epoch, mask_random, mi_masks = build_case(name)
+    from models.Disentangle.STiLModel import STiLModel
+    import models.Disentangle.STiLModel as RM
+
+    class Sched:  # stands in for pl_bolts' LinearWarmupCosineAnnealingLR (absent offline): constructor signature only
+        def __init__(self, optimizer, warmup_epochs, max_epochs):
+            self.optimizer, self.warmup_epochs, self.max_epochs = optimizer, warmup_epochs, max_epochs
+
+    RM.LinearWarmupCosineAnnealingLR = Sched
+    with tempfile.TemporaryDirectory() as td:
+        fl = os.path.join(td, "fl.pt")
+        torch.save(list(hp.field_lengths), fl)
+        rh = ref_hparams(hp, fl)
+        rh.update(scheduler="anneal", warmup_epochs=10, max_epochs=500)
+        model = STiLModel(rh)
+    model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    model.train()
+    model.current_epoch = epoch
+    conf = model.configure_optimizers()
+    opt = conf["optimizer"]
+    orig_rand_like = torch.rand_like
+    torch.rand_like = lambda t, **kw: torch.where(mask_random, torch.full_like(t, 0.75), torch.full_like(t, 0.25))
+    try:
+        opt.zero_grad()
+        model.training_step(batch, 0).backward()
+        opt.step()
+    finally:
+        torch.rand_like = orig_rand_like
+    osd = opt.state_dict()
+    params = [p_ for g in opt.param_groups for p_ in g["params"]]
+    names = {id(p_): n for n, p_ in model.named_parameters()}
+    fx = {"group_sizes": np.array([len(g["params"]) for g in osd["param_groups"]], dtype=np.int64),
+          "lr": np.array([g["lr"] for g in osd["param_groups"]]), "weight_decay": np.array([g["weight_decay"] for g in osd["param_groups"]]),
+          "betas": np.array([g["betas"] for g in osd["param_groups"]]), "eps": np.array([g["eps"] for g in osd["param_groups"]]),
+          "amsgrad": np.array([bool(g["amsgrad"]) for g in osd["param_groups"]]),
+          "ids": np.array([i for g in osd["param_groups"] for i in g["params"]], dtype=np.int64),
+          "numel": np.array([p_.numel() for p_ in params], dtype=np.int64), "ndim": np.array([p_.ndim for p_ in params], dtype=np.int64),
+          "shapes": np.array([d for p_ in params for d in p_.shape], dtype=np.int64),
+          "has_state": np.array([i in osd["state"] for i in range(len(params))]),
+          "names": np.array([names[id(p_)] for p_ in params]),
+          "state_keys": np.array(sorted(next(iter(osd["state"].values())).keys())),
+          "steps": np.array([float(osd["state"][i]["step"]) if i in osd["state"] else 0.0 for i in range(len(params))])}
+    path = os.path.join(ROOT, "tests", "golden", "adam_layout.npz")
+    np.savez_compressed(path, **fx)
+    print(f"[adam_layout:{name}] groups {fx['group_sizes'].tolist()}, {len(params)} parameters, {int(fx['has_state'].sum())} with state, "
+          f"state keys {fx['state_keys'].tolist()} -> {os.path.relpath(path, ROOT)}")
+
+
 if __name__ == "__main__":
     main()
+    adam_layout()

@@ -11,7 +11,7 @@ Random draws are made here (numpy Generator on the host for the few scalars per 
 stil_tab_corrupt_draw for the table) or injected (`draws=`) by the parity tests.  What is pinned to the reference:
 `corrupt` (golden vectors recorded from the reference's own method).  The image transforms follow torchvision's float
 tensor formulas (the reference's non-`augmentation_speedup` branch); albumentations / cv2 / torchvision are absent
-offline, so they are tested against PyTorch restatements only (unpinned), and GaussianBlur is not built.
+offline, so they are tested against PyTorch restatements only (unpinned); the cardiac pipeline's Rotate is not built.
 """
 from __future__ import annotations
 
@@ -109,10 +109,25 @@ def resize_crop(src: torch.Tensor, boxes, P: int, flip=None, jitter=None) -> tor
     return out
 
 
+def gaussian_blur(src: torch.Tensor, sigma, ksize: int = 29) -> torch.Tensor:
+    """transforms.GaussianBlur(ksize, sigma) per sample (sigma[b] <= 0: unchanged) -> float [B,3,H,W] (uint8 sources / 255)."""
+    _chk(src)
+    u8 = src.dtype == torch.uint8
+    B = src.shape[0]
+    H, W = (src.shape[1], src.shape[2]) if u8 else (src.shape[2], src.shape[3])
+    sigma = torch.as_tensor(sigma, dtype=torch.float32).to(src.device).contiguous()
+    tmp = torch.empty((B, 3, H, W), dtype=torch.float32, device=src.device)
+    out = torch.empty_like(tmp)
+    lib().aug_blur(_p(src) if u8 else None, None if u8 else _p(src), _p(sigma), _p(tmp), _p(out), B, H, W, int(ksize), 1.0 / 255.0 if u8 else 1.0,
+                   _stream())
+    return out
+
+
 class ImageAugmenter:
     """grab_image_augmentations (utils/utils.py:46-91) + default_transform (ContrastiveImagingAndTabularDataset.py:66-90):
     dvm: ColorJitter(0.8, 0.8, 0.8) p=0.8, ToGray p=0.2, RandomResizedCrop(scale=(0.08, 1), ratio=(3/4, 4/3)), HFlip p=0.5;
-    cardiac: HFlip p=0.5, ColorJitter(0.5, 0.5, 0.5), RandomResizedCrop(scale=(0.2, 1)).  (GaussianBlur / Rotate: not built.)
+    + GaussianBlur(29, sigma U(0.1, 2)) p=0.5 on the source image; cardiac: HFlip p=0.5, ColorJitter(0.5, 0.5, 0.5),
+    RandomResizedCrop(scale=(0.2, 1))  (its Rotate(45) is not built).
     Every image is augmented with probability `augmentation_rate`, otherwise only resized (generate_imaging_views)."""
 
     def __init__(self, img_size: int, target: str = "dvm", augmentation_rate: float = 1.0, seed: int = 2022):
@@ -130,7 +145,8 @@ class ImageAugmenter:
         on = aug & ((r.random(B) < 0.8) if self.dvm else np.ones(B, dtype=bool))
         jit[:, :3] = np.where(on[:, None], r.uniform(max(0.0, 1.0 - amt), 1.0 + amt, size=(B, 3)), 1.0)
         jit[:, 3] = ((r.random(B) < 0.2) & aug).astype(np.float32) if self.dvm else 0.0
-        return dict(boxes=boxes, flip=flip, jitter=jit)
+        sigma = np.where(aug & (r.random(B) < 0.5), r.uniform(0.1, 2.0, size=B), 0.0).astype(np.float32) if self.dvm else np.zeros(B, np.float32)
+        return dict(boxes=boxes, flip=flip, jitter=jit, sigma=sigma)
 
     def __call__(self, src: torch.Tensor, draws: Optional[Dict[str, np.ndarray]] = None):
         """-> (augmented view, unaugmented resized image), both float [B,3,P,P]."""
@@ -138,7 +154,9 @@ class ImageAugmenter:
         B = src.shape[0]
         H, W = (src.shape[1], src.shape[2]) if u8 else (src.shape[2], src.shape[3])
         d = draws or self.draw(B, H, W)
-        view = resize_crop(src, d["boxes"], self.P, d.get("flip"), d.get("jitter"))
+        sg = d.get("sigma")
+        blurred = gaussian_blur(src, sg) if (sg is not None and float(np.max(sg)) > 0.0 and min(H, W) > 14) else src
+        view = resize_crop(blurred, d["boxes"], self.P, d.get("flip"), d.get("jitter"))
         full = np.tile(np.array([[0, 0, H, W]], dtype=np.int32), (B, 1))
         return view, resize_crop(src, full, self.P)
 

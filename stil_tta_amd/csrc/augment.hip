@@ -146,6 +146,47 @@ __global__ __launch_bounds__(256) void aug_gray_mean_kernel(AugArgs p, float* __
   if (threadIdx.x == 0) gmean[b] = s / (float)(p.H * p.W);
 }
 
+// ---------------------------------------------------------------- Gaussian blur (utils/utils.py:52, transforms.GaussianBlur(29, (0.1, 2.0)))
+// Separable: one launch per direction.  Weights as torchvision's _get_gaussian_kernel1d: exp(-0.5 (x / sigma)^2) over
+// x = -(k-1)/2 .. (k-1)/2, normalised; borders are mirrored without repeating the edge pixel ("reflect").  sigma[b] <= 0
+// copies sample b unchanged (the transform is applied with probability 0.5).  Pass 0 reads the source (uint8 HWC or float
+// CHW, scaled by `scale`) along rows, pass 1 reads the float CHW intermediate along columns.
+__global__ __launch_bounds__(256) void aug_blur_kernel(AugArgs p, const float* __restrict__ sigma, const float* __restrict__ mid,
+                                                        float* __restrict__ dst, int ksize, int vertical) {
+  __shared__ float wgt[64];
+  const int b = blockIdx.y, half = ksize >> 1;
+  const float sg = sigma[b];
+  if (threadIdx.x < ksize) {
+    const float x = (float)((int)threadIdx.x - half);
+    wgt[threadIdx.x] = sg > 0.f ? expf(-0.5f * (x / sg) * (x / sg)) : (threadIdx.x == half ? 1.f : 0.f);
+  }
+  __syncthreads();
+  float wsum = 0.f;
+  for (int t = 0; t < ksize; ++t) wsum += wgt[t];   // fixed order: every thread gets the same normaliser
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= p.H * p.W) return;
+  const int y = pix / p.W, x0 = pix - y * p.W;
+  const long plane = (long)p.H * p.W;
+  float acc[3] = {0.f, 0.f, 0.f};
+  for (int t = 0; t < ksize; ++t) {
+    int yy = y, xx = x0;
+    if (vertical) { yy = y + t - half; if (yy < 0) yy = -yy; if (yy >= p.H) yy = 2 * p.H - 2 - yy; }
+    else { xx = x0 + t - half; if (xx < 0) xx = -xx; if (xx >= p.W) xx = 2 * p.W - 2 - xx; }
+    float v[3];
+    if (vertical) {
+      const float* q = mid + (long)b * 3 * plane + (long)yy * p.W + xx;
+      v[0] = q[0]; v[1] = q[plane]; v[2] = q[2 * plane];
+    } else {
+      aug_fetch(p, b, yy, xx, v);
+      v[0] *= p.scale; v[1] *= p.scale; v[2] *= p.scale;
+    }
+    const float wt = wgt[t] / wsum;
+    acc[0] += wt * v[0]; acc[1] += wt * v[1]; acc[2] += wt * v[2];
+  }
+  float* o = dst + (long)b * 3 * plane + pix;
+  o[0] = acc[0]; o[plane] = acc[1]; o[2 * plane] = acc[2];
+}
+
 // ---------------------------------------------------------------- C ABI
 extern "C" int stil_tab_corrupt(const float* clean, const float* marginal, const int* idx, const int* pos, float* out,
                                 int B, int n_cols, int n_rows, int k, void* stream) {
@@ -189,6 +230,20 @@ extern "C" int stil_aug_resize(const unsigned char* src_u8, const float* src_f32
   if (rc) return rc;
   STIL_REQUIRE(!jitter || gmean, "stil_aug_resize: colour jitter needs gmean (stil_aug_gray_mean)");
   hipLaunchKernelGGL(aug_resize_kernel, dim3(cdiv((long)P * P, 256), B), dim3(256), 0, (hipStream_t)stream, p);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" int stil_aug_blur(const unsigned char* src_u8, const float* src_f32, const float* sigma, float* tmp, float* out, int B, int H,
+                             int W, int ksize, float scale, void* stream) {
+  STIL_REQUIRE((src_u8 != nullptr) != (src_f32 != nullptr) && sigma && tmp && out && B > 0, "stil_aug_blur: bad arguments");
+  STIL_REQUIRE(ksize % 2 == 1 && ksize >= 3 && ksize <= 63 && ksize / 2 < H && ksize / 2 < W,
+               "stil_aug_blur: kernel size %d must be odd, in [3, 63] and its radius smaller than the image (%d x %d)", ksize, H, W);
+  AugArgs p{src_u8, src_f32, nullptr, nullptr, nullptr, nullptr, nullptr, H, W, 1, scale};
+  const dim3 grid(cdiv((long)H * W, 256), B);
+  hipLaunchKernelGGL(aug_blur_kernel, grid, dim3(256), 0, (hipStream_t)stream, p, sigma, (const float*)nullptr, tmp, ksize, 0);
+  STIL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(aug_blur_kernel, grid, dim3(256), 0, (hipStream_t)stream, p, sigma, (const float*)tmp, out, ksize, 1);
   STIL_LAUNCH_CHECK();
   return STIL_OK;
 }

@@ -62,8 +62,8 @@ class MMatch(STiLModel):
             self.save_hyperparameters(vars(hp))
         else:
             self.hparams = hp
-            self._epoch = 0
-            self.logged: Dict[str, torch.Tensor] = {}
+        self._epoch = 0                                  # private epoch / log store (stil_model.STiLModel plumbing)
+        self.logged: Dict[str, torch.Tensor] = {}
         self.hp = hp
         fl = getattr(hp, "field_lengths", None)
         if fl is None:
@@ -229,8 +229,8 @@ class CoTraining(STiLModel):
             self.save_hyperparameters(vars(hp))
         else:
             self.hparams = hp
-            self._epoch = 0
-            self.logged: Dict[str, torch.Tensor] = {}
+        self._epoch = 0                                  # private epoch / log store (stil_model.STiLModel plumbing)
+        self.logged: Dict[str, torch.Tensor] = {}
         self.hp = hp
         fl = getattr(hp, "field_lengths", None)
         if fl is None:

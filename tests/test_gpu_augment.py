@@ -110,6 +110,28 @@ def test_colour_jitter_matches_torchvision_float_formulas():
     assert torch.equal(got[2], resize_crop(src.cuda(), boxes, P).cpu()[2])   # identity factors change nothing
 
 
+def test_gaussian_blur_matches_torchvision_formula():
+    from stil_tta_amd.augment import gaussian_blur
+    g = torch.Generator().manual_seed(5)
+    B, H, W, k = 4, 50, 37, 29
+    u8 = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
+    sigma = torch.tensor([0.1, 2.0, 0.0, 0.9])
+    got = gaussian_blur(u8.cuda(), sigma, k).cpu()
+    src = u8.permute(0, 3, 1, 2).float() / 255.0
+    for b in range(B):
+        if float(sigma[b]) <= 0:   # copied (x * (1/255) on the device vs x / 255 here: one ulp)
+            assert float((got[b] - src[b]).abs().max()) <= 1.2e-7
+            continue
+        x = torch.linspace(-(k - 1) * 0.5, (k - 1) * 0.5, k)
+        w1 = torch.exp(-0.5 * (x / sigma[b]) ** 2)
+        w1 = w1 / w1.sum()
+        pad = F.pad(src[b:b + 1], (k // 2, k // 2, k // 2, k // 2), mode="reflect")
+        ref = F.conv2d(pad, (w1[:, None] * w1[None, :]).expand(3, 1, k, k).contiguous(), groups=3)[0]
+        assert float((got[b] - ref).abs().max()) <= 3e-6, b
+    f32 = torch.rand(2, 3, 40, 40, generator=g)
+    assert float((gaussian_blur(f32.cuda(), [1.3, 0.0], 9).cpu()[1] - f32[1]).abs().max()) == 0.0
+
+
 def test_batch_builder_feeds_the_training_step():
     """ContrastiveBatchBuilder yields the reference's part tuple; a step on its output runs and is finite."""
     from stil_tta_amd import STiLModel

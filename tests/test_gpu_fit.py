@@ -132,3 +132,44 @@ def test_device_prefetcher_preserves_batches_and_order():
         assert torch.equal(y.cpu(), ref["l"][2]) and torch.equal(orig.cpu(), ref["l"][3])
         seen += 1
     assert seen == 7
+
+
+def test_optimizer_state_layout_equals_the_references_adam():
+    """`optimizer_states[0]` of a checkpoint written by fit.save_checkpoint against torch.optim.Adam.state_dict() of the
+    REFERENCE's own configure_optimizers (STiLModel.py:557-577) after one step, recorded by oracle/make_golden.py
+    (tests/golden/adam_layout.npz): six parameter groups with the same sizes / ids / hyper-parameters, the same parameter
+    shapes in id order, state for exactly the parameters that received a gradient, the same state keys and step counts."""
+    import numpy as np
+    from oracle.make_golden import build_case
+    from stil_tta_amd import STiLModel, fit as F
+    from stil_tta_amd.driver import train_step
+    from stil_tta_amd.flat import StilAdam
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "adam_layout.npz"))
+    hp, sd, batch, epoch, mask_random, mi_masks = build_case("dvm_r18_noeman")
+    m = STiLModel(dict(vars(hp), mi_dropout=False))
+    m.load_state_dict(sd)
+    m.setup_device("cuda"); m.train(); m.current_epoch = epoch
+    opt = StilAdam(m.flat, lr=hp.lr_eval, weight_decay=hp.weight_decay_eval)
+    dev_batch = {k: ([v[0][0].cuda(), v[0][1].cuda()], [v[1][0].cuda(), v[1][1].cuda()], v[2].cuda(), v[3].cuda(), v[4].cuda()) for k, v in batch.items()}
+    train_step(m, opt, dev_batch, mask_random=mask_random)
+    torch.cuda.synchronize()
+    osd = F.adam_state_dict(m, opt)
+    groups = osd["param_groups"]
+    assert [len(g["params"]) for g in groups] == fx["group_sizes"].tolist()
+    assert [i for g in groups for i in g["params"]] == fx["ids"].tolist()
+    for gi, g in enumerate(groups):
+        assert g["lr"] == float(fx["lr"][gi]) and g["weight_decay"] == float(fx["weight_decay"][gi])
+        assert tuple(g["betas"]) == tuple(fx["betas"][gi]) and g["eps"] == float(fx["eps"][gi])
+    order = [p for mod in (m.model, m.projector_imaging, m.projector_tabular, m.projector_multimodal, m.CLUB_imaging, m.CLUB_tabular)
+             for p in mod.parameters()]
+    assert [p.numel() for p in order] == fx["numel"].tolist()
+    assert [d for p in order for d in p.shape] == fx["shapes"].tolist()
+    names = {id(p): n for n, p in m.named_parameters()}
+    assert [names[id(p)] for p in order] == fx["names"].tolist()
+    has = np.array([i in osd["state"] for i in range(len(order))])
+    assert np.array_equal(has, fx["has_state"]), [fx["names"][i] for i in np.nonzero(has != fx["has_state"])[0]]
+    st = osd["state"][int(np.nonzero(has)[0][0])]
+    assert sorted(st.keys()) == fx["state_keys"].tolist()
+    assert [float(osd["state"][i]["step"]) if i in osd["state"] else 0.0 for i in range(len(order))] == fx["steps"].tolist()
+    for i in np.nonzero(has)[0][:5]:
+        assert tuple(osd["state"][int(i)]["exp_avg"].shape) == tuple(order[int(i)].shape)
