@@ -67,15 +67,15 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
 }
 
 // stats[0]=mean, [1]=rstd, [2]=a=gamma*rstd, [3]=beta ; updates running stats (momentum, unbiased var)
-__global__ __launch_bounds__(1024) void bn_stats_final_kernel(const float* __restrict__ Kp, const float* __restrict__ part, int nch, int M, int C,
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ Kp, const float* __restrict__ part, int nch, int M, int C,
                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                       float* __restrict__ rmean, float* __restrict__ rvar, long long* nbt,
                                       float* __restrict__ stats, float eps, float momentum) {
-  __shared__ float sh[2 * 32 * 32];
+  __shared__ float sh[2 * 8 * 32];
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
   int c;
   float tot[2];
-  if (!chunk_reduce<32, 2>(part, nch, C, sh, c, tot)) return;
+  if (!chunk_reduce<8, 2>(part, nch, C, sh, c, tot)) return;
   const float s1 = tot[0], s2 = tot[1];
   const float invM = 1.f / (float)M;
   const float d = s1 * invM;
@@ -96,24 +96,27 @@ __global__ __launch_bounds__(1024) void bn_stats_final_kernel(const float* __res
 // With n_t rows in tile t:  mean = S1/M,  M2 = S3 + (S2 - S1^2/M),  S1 = sum n_t mean_t, S2 = sum n_t mean_t^2, S3 = sum M2_t.
 // The three sums run in DOUBLE (every term is an exact product of floats, so the S2 - S1^2/M cancellation costs nothing),
 // split over `nsplit` blocks per 32 columns (stage 1) and added in a fixed order (stage 2): deterministic.
-__global__ __launch_bounds__(1024) void bn_tiles_stage1_kernel(const float* __restrict__ ts, int nt, int tile_rows, int M, int C,
+// 256-thread workgroups (8 row lanes x 32 columns): these short dependent kernels run while the other stream's GEMM keeps
+// every CU full of 256-thread workgroups -- a 1024-thread workgroup had to wait for four of them to retire on ONE CU
+// (55 us instead of 8 us per launch under the two-stream step).
+__global__ __launch_bounds__(256) void bn_tiles_stage1_kernel(const float* __restrict__ ts, int nt, int tile_rows, int M, int C,
                                                                 int tiles_per_split, double* __restrict__ part) {
-  __shared__ double sh[3 * 32 * 32];
+  __shared__ double sh[3 * 8 * 32];
   const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   const int t0 = blockIdx.y * tiles_per_split, t1 = min(nt, t0 + tiles_per_split);
   double s1 = 0.0, s2 = 0.0, s3 = 0.0;
   if (c < C)
-    for (int t = t0 + lane; t < t1; t += 32) {
+    for (int t = t0 + lane; t < t1; t += 8) {
       const double n = (double)min(tile_rows, M - t * tile_rows);
       const double m = (double)ts[((long)t * 2) * C + c];
       s1 += n * m; s2 += n * m * m; s3 += (double)ts[((long)t * 2 + 1) * C + c];
     }
-  sh[lane * 32 + cl] = s1; sh[1024 + lane * 32 + cl] = s2; sh[2048 + lane * 32 + cl] = s3;
+  sh[lane * 32 + cl] = s1; sh[256 + lane * 32 + cl] = s2; sh[512 + lane * 32 + cl] = s3;
   __syncthreads();
   if (lane != 0 || c >= C) return;
   double a = 0.0, b = 0.0, d = 0.0;
-  for (int l = 0; l < 32; ++l) { a += sh[l * 32 + cl]; b += sh[1024 + l * 32 + cl]; d += sh[2048 + l * 32 + cl]; }
+  for (int l = 0; l < 8; ++l) { a += sh[l * 32 + cl]; b += sh[256 + l * 32 + cl]; d += sh[512 + l * 32 + cl]; }
   const int nsplit = gridDim.y;
   part[((long)0 * nsplit + blockIdx.y) * C + c] = a;
   part[((long)1 * nsplit + blockIdx.y) * C + c] = b;
@@ -226,14 +229,14 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 }
 
 // dgamma/dbeta (+)= ; coef[0]=gamma*rstd, [1]=dbeta/M, [2]=dgamma/M
-__global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const float* __restrict__ part, int nch, int M, int C,
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ part, int nch, int M, int C,
                                     const float* __restrict__ gamma, const float* __restrict__ stats,
                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef,
                                     int accumulate) {
-  __shared__ float sh[2 * 32 * 32];
+  __shared__ float sh[2 * 8 * 32];
   int c;
   float tot[2];
-  if (!chunk_reduce<32, 2>(part, nch, C, sh, c, tot)) return;
+  if (!chunk_reduce<8, 2>(part, nch, C, sh, c, tot)) return;
   const float s1 = tot[0], s2 = tot[1];
   if (dbeta) dbeta[c] = accumulate ? dbeta[c] + s1 : s1;
   if (dgamma) dgamma[c] = accumulate ? dgamma[c] + s2 : s2;
@@ -420,7 +423,7 @@ extern "C" int stil_bn_train_fwd(const float* x, const float* gamma, const float
   STIL_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C / ct, nch), dim3(256), 0, s, x, pilot, workspace, M, C, ct, rpc);
   STIL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, s, pilot, workspace, nch, M, C, gamma, beta,
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 32)), dim3(256), 0, s, pilot, workspace, nch, M, C, gamma, beta,
                      running_mean, running_var, num_batches_tracked, stats, eps, momentum);
   STIL_LAUNCH_CHECK();
   long total4 = (long)M * C / 4;
@@ -440,7 +443,7 @@ extern "C" int stil_bn_eval_affine(const float* gamma, const float* beta, const 
 }
 
 // Training forward when the producing GEMM already wrote per-tile statistics (tilestats: [2*cdiv(M,tile_rows), C]).
-static inline int bn_tiles_nsplit(int nt) { return cdiv(nt, 512); }
+static inline int bn_tiles_nsplit(int nt) { return cdiv(nt, 256); }
 extern "C" size_t stil_bn_tiles_workspace_bytes(int M, int C, int tile_rows) {
   if (M <= 0 || C <= 0 || tile_rows <= 0) return 0;
   return (size_t)3 * bn_tiles_nsplit(cdiv(M, tile_rows)) * C * sizeof(double);
@@ -455,7 +458,7 @@ extern "C" int stil_bn_train_fwd_tiles(const float* x, const float* tilestats, i
                "stil_bn_train_fwd_tiles: workspace too small or not 8-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const int nt = cdiv(M, tile_rows), nsplit = bn_tiles_nsplit(nt);
-  hipLaunchKernelGGL(bn_tiles_stage1_kernel, dim3(cdiv(C, 32), nsplit), dim3(1024), 0, s, tilestats, nt, tile_rows, M, C,
+  hipLaunchKernelGGL(bn_tiles_stage1_kernel, dim3(cdiv(C, 32), nsplit), dim3(256), 0, s, tilestats, nt, tile_rows, M, C,
                      cdiv(nt, nsplit), (double*)workspace);
   STIL_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_tiles_stage2_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)workspace, nsplit, M, C, gamma, beta,
@@ -486,7 +489,7 @@ extern "C" int stil_bn_train_bwd(const float* dz, const float* z, const float* x
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C / ct, nch), dim3(256), 0, s, dz, z, x, stats, gout, workspace, M, C,
                      ct, rpc, relu);
   STIL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, s, workspace, nch, M, C, gamma, stats, dgamma,
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 32)), dim3(256), 0, s, workspace, nch, M, C, gamma, stats, dgamma,
                      dbeta, coef, accumulate);
   STIL_LAUNCH_CHECK();
   long total4 = (long)M * C / 4;

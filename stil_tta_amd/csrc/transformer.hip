@@ -56,13 +56,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     part[(long)blockIdx.x * 2 * D + i] = sh[i] + sh[2 * D + i] + sh[4 * D + i] + sh[6 * D + i];
 }
 
-__global__ __launch_bounds__(1024) void ln_final_kernel(const float* __restrict__ part, int nblk, int D, float* __restrict__ dgamma,
+__global__ __launch_bounds__(256) void ln_final_kernel(const float* __restrict__ part, int nblk, int D, float* __restrict__ dgamma,
                                 float* __restrict__ dbeta, int accumulate) {
   // part: [nblk][2][D]  ->  view as 2*D columns of nblk chunks
-  __shared__ float sh[32 * 32];
+  __shared__ float sh[8 * 32];
   int c;
   float tot[1];
-  if (!chunk_reduce<32, 1>(part, nblk, 2 * D, sh, c, tot)) return;
+  if (!chunk_reduce<8, 1>(part, nblk, 2 * D, sh, c, tot)) return;
   float* dst = c < D ? dgamma + c : dbeta + (c - D);
   *dst = accumulate ? *dst + tot[0] : tot[0];
 }
@@ -712,7 +712,7 @@ extern "C" int stil_layernorm_bwd(const float* g, const float* x, const float* g
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), (size_t)8 * D * sizeof(float), s, g, x, gamma, mean_rstd,
                      dx, workspace, rows, D, rpb);
   STIL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ln_final_kernel, dim3(cdiv(2 * D, 32)), dim3(1024), 0, s, workspace, nb, D, dgamma, dbeta, accumulate);
+  hipLaunchKernelGGL(ln_final_kernel, dim3(cdiv(2 * D, 32)), dim3(256), 0, s, workspace, nb, D, dgamma, dbeta, accumulate);
   STIL_LAUNCH_CHECK();
   return STIL_OK;
 }
