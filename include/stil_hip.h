@@ -205,6 +205,18 @@ int stil_proto_add(const float* class_sum_cnt, float* prototypes_sum, float* pro
 int stil_proto_commit(float* prototypes, float* prototypes_sum, float* prototypes_count_sum,
                       int* bad_count_dev, int K, int Dp, void* stream);
 
+/* CoMatch's pseudo-label-graph contrastive loss (models/MatchModel/CoMatch.py:104-117) on S = f_s0 . [f_s1 ; queue_s]^T / T
+ * [rows, N] and the pseudo-label graph Q [rows, N] (comatch_model.py:287-297): row_loss[r] = -sum_j log(p_rj + 1e-7) w_rj over
+ * the edges Q >= threshold, p = exp(S) / rowsum(exp(S)), w = Q / rowsum(Q over the edges); dS (optional) = d(mean row_loss)/dS
+ * with inv_rows = 1/rows. */
+int stil_contrast_graph(const float* S, int lds, const float* Q, int ldq, float threshold, float* row_loss, float* dS,
+                        int ldd, int rows, int N, float inv_rows, void* stream);
+/* SimMatch's label unfolding / aggregation (models/MatchModel/simmatch_model.py:289-302): teacher[r,j] = tpo[r,j] * probs[r,
+ * labels[j]] renormalised per row (tpo [rows, N] = softmax(feat_ku . bank / tt), labels [N] = the bank's class ids);
+ * pseudo[r,k] (optional) = probs[r,k] * c_smooth + (sum of tpo[r,j] with labels[j] == k) * (1 - c_smooth), or probs when
+ * c_smooth >= 1. */
+int stil_simmatch_unfold(const float* tpo, const float* probs, const long long* labels, float* teacher, float* pseudo,
+                         int rows, int N, int K, float c_smooth, void* stream);
 /* logged partition ratios (STiLModel.py:307-311) from cgpl_pgls's flags [rows,ld] = (case id 1..4, mask1, ...):
  * out5 = {threshold1_ratio, case1_ratio, case2_i_ratio, case2_t_ratio, case3_ratio} */
 int stil_flag_ratios(const unsigned char* flags, int ld, int rows, float* out5, void* stream);

@@ -561,6 +561,87 @@ extern "C" int stil_onehot_argmax(const float* probs, int rows, int K, float thr
 }
 
 
+// ---------------------------------------------------------------- CoMatch / SimMatch baselines
+// CoMatch pseudo-label-graph contrastive loss (models/MatchModel/CoMatch.py:104-117) on S = f_s0 . [f_s1 ; queue_s]^T / T:
+//   sim = exp(S);  m = (Q >= th);  w = Q m / sum_j(Q m);  p = sim m / sum_j sim;  row_loss = -sum_j log(p + 1e-7) m w
+//   dS  = (softmax(S) * Csum - c) * inv_rows,   c = w p / (p + 1e-7),   Csum = sum_j c
+// One block per unlabelled sample; the diagonal of Q is 1, so every row has at least one positive.
+__global__ __launch_bounds__(256) void contrast_graph_kernel(const float* __restrict__ S, int lds, const float* __restrict__ Q, int ldq,
+                                                              float th, float* __restrict__ row_loss, float* __restrict__ dS, int ldd,
+                                                              int N, float inv_rows) {
+  __shared__ float red[16];
+  const int r = blockIdx.x;
+  const float* sr = S + (long)r * lds;
+  const float* qr = Q + (long)r * ldq;
+  float D = 0.f, Qs = 0.f;
+  for (int j = threadIdx.x; j < N; j += 256) {
+    D += expf(sr[j]);
+    const float q = qr[j];
+    Qs += q >= th ? q : 0.f;
+  }
+  D = block_sum(D, red);
+  Qs = block_sum(Qs, red);
+  float a = 0.f, C = 0.f;
+  for (int j = threadIdx.x; j < N; j += 256) {
+    const float q = qr[j];
+    if (q >= th) {
+      const float p = expf(sr[j]) / D, w = q / Qs;
+      a += logf(p + 1e-7f) * w;
+      C += w * (p / (p + 1e-7f));
+    }
+  }
+  a = block_sum(a, red);
+  C = block_sum(C, red);
+  if (threadIdx.x == 0) row_loss[r] = -a;
+  if (dS)
+    for (int j = threadIdx.x; j < N; j += 256) {
+      const float q = qr[j], sm = expf(sr[j]) / D;
+      const float c = q >= th ? (q / Qs) * (sm / (sm + 1e-7f)) : 0.f;
+      dS[(long)r * ldd + j] = (sm * C - c) * inv_rows;
+    }
+}
+
+extern "C" int stil_contrast_graph(const float* S, int lds, const float* Q, int ldq, float threshold, float* row_loss, float* dS,
+                                   int ldd, int rows, int N, float inv_rows, void* stream) {
+  STIL_REQUIRE(S && Q && row_loss && rows > 0 && N > 0 && lds >= N && ldq >= N && (!dS || ldd >= N), "stil_contrast_graph: bad arguments");
+  hipLaunchKernelGGL(contrast_graph_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, S, lds, Q, ldq, threshold, row_loss, dS, ldd,
+                     N, inv_rows);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+// SimMatch label unfolding / aggregation (models/MatchModel/simmatch_model.py:289-302) for one unlabelled sample per block:
+//   teacher[j] = tpo[j] * p[labels[j]] / sum_j(..)        (tpo = softmax(feat_ku . bank / tt), p = aligned class probabilities)
+//   pseudo[k]  = p[k] * c + (sum_{j: labels[j] == k} tpo[j]) * (1 - c)    (bank entries added in index order, like scatter_add)
+__global__ __launch_bounds__(256) void simmatch_unfold_kernel(const float* __restrict__ tpo, const float* __restrict__ p,
+                                                               const long long* __restrict__ labels, float* __restrict__ teacher,
+                                                               float* __restrict__ pseudo, int N, int K, float c_smooth) {
+  __shared__ float red[16];
+  const int r = blockIdx.x;
+  const float* tr = tpo + (long)r * N;
+  const float* pr = p + (long)r * K;
+  float s = 0.f;
+  for (int j = threadIdx.x; j < N; j += 256) s += tr[j] * pr[labels[j]];
+  s = block_sum(s, red);
+  for (int j = threadIdx.x; j < N; j += 256) teacher[(long)r * N + j] = tr[j] * pr[labels[j]] / s;
+  if (pseudo)
+    for (int k = threadIdx.x; k < K; k += 256) {
+      float acc = 0.f;
+      if (c_smooth < 1.f)
+        for (int j = 0; j < N; ++j) acc += labels[j] == k ? tr[j] : 0.f;
+      pseudo[(long)r * K + k] = c_smooth < 1.f ? pr[k] * c_smooth + acc * (1.f - c_smooth) : pr[k];
+    }
+}
+
+extern "C" int stil_simmatch_unfold(const float* tpo, const float* probs, const long long* labels, float* teacher, float* pseudo,
+                                    int rows, int N, int K, float c_smooth, void* stream) {
+  STIL_REQUIRE(tpo && probs && labels && teacher && rows > 0 && N > 0 && K > 0, "stil_simmatch_unfold: bad arguments");
+  hipLaunchKernelGGL(simmatch_unfold_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, tpo, probs, labels, teacher, pseudo, N, K,
+                     c_smooth);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
 // ---- logged partition ratios (STiLModel.py:307-311): out = {mean(mask1), mean(case == 1), .. == 2, .. == 3, .. == 4}
 // flags: [rows, ld] bytes, columns (CGPL case id 1..4, mask1, ...) as written by cgpl_pgls_kernel.  One block, fixed order.
 __global__ __launch_bounds__(256) void flag_ratios_kernel(const unsigned char* __restrict__ flags, int ld, int rows, float* __restrict__ out) {

@@ -296,8 +296,8 @@ class MatmulNTFn(torch.autograd.Function):
         M, K = A.shape
         N = B.shape[0]
         gZ = gZ.contiguous()
-        dA = gemm_nt(gZ, transpose(B), M, K, N, alpha=ctx.alpha)          # gZ [M,N] . B [N,K]
-        dB = gemm_nt(transpose(gZ), transpose(A), N, K, M, alpha=ctx.alpha)  # gZ^T [N,M] . A [M,K]
+        dA = gemm_nt(gZ, transpose(B), M, K, N, alpha=ctx.alpha) if ctx.needs_input_grad[0] else None            # gZ [M,N] . B [N,K]
+        dB = gemm_nt(transpose(gZ), transpose(A), N, K, M, alpha=ctx.alpha) if ctx.needs_input_grad[1] else None  # gZ^T [N,M] . A [M,K]
         return dA, dB, None
 
 
@@ -797,6 +797,38 @@ class ClipFromLogitsFn(torch.autograd.Function):
         dZ = torch.empty_like(Z)
         lib().clip_bwd(_p(Z), _p(lse), _p(g.contiguous()), _p(dZ), Z.shape[0], ctx.lam0, 1.0 - ctx.lam0, _stream())
         return dZ, None
+
+
+class ContrastGraphFn(torch.autograd.Function):
+    """CoMatch's pseudo-label-graph contrastive loss (models/MatchModel/CoMatch.py:104-117) from S = log(sim) and the graph Q."""
+
+    @staticmethod
+    def forward(ctx, S, Q, threshold):
+        _chk(S, Q)
+        R, N = S.shape
+        rl = torch.empty((R,), dtype=torch.float32, device=S.device)
+        dS = torch.empty_like(S)
+        lib().contrast_graph(_p(S), N, _p(Q), N, float(threshold), _p(rl), _p(dS), N, R, N, 1.0 / R, _stream())
+        loss = torch.empty((), dtype=torch.float32, device=S.device)
+        lib().reduce_sum(_p(rl), R, 1.0 / R, _p(loss), 0, _stream())
+        ctx.save_for_backward(dS)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dS,) = ctx.saved_tensors
+        return _scale_by(dS, g), None, None
+
+
+def simmatch_unfold(tpo, probs, labels, c_smooth):
+    """-> teacher_prob [R,N], pseudo-label [R,K]  (models/MatchModel/simmatch_model.py:289-302); no gradient."""
+    _chk(tpo, probs, labels)
+    R, N = tpo.shape
+    K = probs.shape[1]
+    teacher = torch.empty_like(tpo)
+    pseudo = torch.empty_like(probs)
+    lib().simmatch_unfold(_p(tpo), _p(probs), _p(labels), _p(teacher), _p(pseudo), R, N, K, float(c_smooth), _stream())
+    return teacher, pseudo
 
 
 def clip_loss(f0, f1, T, lam0, gather=False):

@@ -166,3 +166,51 @@ def test_tab_corrupt_restatement_matches_reference_golden():
         for s in range(len(out)):
             assert len(set(idx[s].tolist())) == idx.shape[1]        # random.sample: distinct columns
             assert np.array_equal(corrupt_oracle(table[s % len(table)], table.T, idx[s], pos[s]), out[s])
+
+
+# ---------------------------------------------------------------- CoMatch / SimMatch baselines
+from oracle import match_oracle as XO  # noqa: E402
+from oracle import make_golden_match as GX  # noqa: E402
+
+
+def _match_case(name):
+    fx = np.load(os.path.join(GOLD, name + ".npz"))
+    kind, hp, sd, batch, epoch, aux = GX.build_case(name)
+    for nm in ("co_threshold", "contrast_th", "sim_threshold"):   # data-dependent thresholds of the generating machine
+        setattr(hp, nm, float(fx["meta_" + nm]))
+    return fx, kind, hp, sd, batch, epoch, aux
+
+
+@pytest.mark.parametrize("name", list(GX.CASES))
+def test_match_oracle_matches_reference_golden(name):
+    fx, kind, hp, sd, batch, epoch, aux = _match_case(name)
+    out = XO.full_step(kind, sd, {}, 1, batch, hp, epoch, aux=aux)
+    scalars, tensors = GX.OUT[kind]
+    for k in scalars:
+        assert _close(out[k].numpy(), fx["out_" + k], 2e-5), k
+    for k in tensors:
+        assert _close(out[k].numpy(), fx["out_" + k], 2e-5), k
+    for key in fx.files:
+        if key.startswith("gnorm_"):
+            g = out["grads"].get(key[6:])
+            n = 0.0 if g is None else float(g.double().norm())
+            assert abs(n - float(fx[key])) <= 1e-4 * (1e-6 + float(fx[key])) + 1e-7, key
+        elif key.startswith("ssum_"):
+            assert abs(float(sd[key[5:]].double().sum()) - float(fx[key])) <= 2e-5 * (1.0 + float(fx["sabs_" + key[5:]])), key
+        elif key.startswith("state_"):
+            a, b = sd[key[6:]].numpy(), fx[key]
+            assert (np.array_equal(a, b) if b.dtype == np.int64 else _close(a, b, 2e-5)), key
+    if kind == "comatch":
+        assert len(aux["hist_prob"]) == int(fx["hist_len"]) and _close(aux["hist_prob"][-1].numpy(), fx["hist_last"], 2e-5)
+
+
+@pytest.mark.parametrize("name", ["comatch_r18_bank", "comatch_r18_img_binary", "simmatch_r18_bank", "simmatch_r18_img_noDA"])
+def test_match_state_dict_layout(name):
+    import stil_tta_amd
+    kind, over, _, _, _ = GX.CASES[name]
+    hp = XO.default_hparams(**over)
+    sd = (XO.comatch_init_state if kind == "comatch" else XO.simmatch_init_state)(hp, seed=0)
+    m = (stil_tta_amd.CoMatch if kind == "comatch" else stil_tta_amd.SimMatch)(dict(vars(hp)))
+    got = m.state_dict()
+    assert list(got.keys()) == list(sd.keys())
+    assert all(tuple(got[k].shape) == tuple(sd[k].shape) for k in sd)
