@@ -196,8 +196,9 @@ def broadcast_state(model, optimizer=None):
         dist.broadcast(t, src=0)
     for b in list(f.s_counters) + list(f.t_counters):
         dist.broadcast(b, src=0)
-    for name, b in model.named_buffers():
-        if name.startswith(("prototypes", "DA_")) or name in ("queue", "queue_ptr"):
+    slabs = {f.params.untyped_storage().data_ptr(), f.ema.untyped_storage().data_ptr()}
+    for _, b in model.named_buffers():       # prototypes, DA queue, the baselines' memory banks / queues and their pointers
+        if b.untyped_storage().data_ptr() not in slabs:
             dist.broadcast(b, src=0)
 
 

@@ -157,3 +157,60 @@ def test_contrast_graph_and_unfold_kernels_against_torch():
             ps = p.double() * c + agg * (1 - c) if c < 1 else p.double()
             assert float((t_d.cpu().double() - t).abs().max()) <= 1e-6
             assert float((ps_d.cpu().double() - ps).abs().max()) <= 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------- two ranks
+def _dp_worker(rank, world, port, outdir):
+    """concat_all_gather / all_reduce paths of comatch_model.py:114-118,265-270 and simmatch_model.py:137-156 on two ranks."""
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      STIL_DIST_BACKEND="gloo")
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import stil_tta_amd
+    from stil_tta_amd.driver import init_distributed, train_step
+    from stil_tta_amd.flat import StilAdam
+    init_distributed()
+    out = {}
+    for kind, cls in (("comatch", stil_tta_amd.CoMatch), ("simmatch", stil_tta_amd.SimMatch)):
+        hp = XO.default_hparams(**dict(GX.R18, K=40, contrast_th=0.3, co_threshold=0.3, sim_threshold=0.3))
+        torch.manual_seed(rank)          # differently initialised ranks: the first step broadcasts rank 0's state
+        m = cls(dict(vars(hp)))
+        m.setup_device("cuda"); m.train(); m.current_epoch = 2
+        batch = XO.synthetic_batch(hp, 16, seed=70 + rank, views=3 if kind == "comatch" else 2)
+        if kind == "simmatch":           # disjoint bank slots per rank
+            batch["l"] = (batch["l"][0], batch["l"][1], torch.tensor([3 + rank, 20 + rank]))
+        dbatch = {"l": tuple(_dev(t) for t in batch["l"]), "u": (_dev(batch["u"][0]), batch["u"][1].cuda())}
+        train_step(m, StilAdam(m.flat, lr=1e-3), dbatch)
+        torch.cuda.synchronize()
+        sd = {k: v.cpu() for k, v in m.state_dict().items() if "encoder" not in k and ".main." not in k and ".ema." not in k}
+        out[kind] = dict(state=sd, params=m.flat.params.cpu(), probs=m.last["probs" if kind == "comatch" else "prob_ku_orig"].cpu(),
+                         nb=(m.flat.n_backbone_params, m.flat.n_backbone_state))
+        if kind == "comatch":
+            out[kind]["hist"] = m.model.hist_prob[-1].cpu()
+    torch.save(out, os.path.join(outdir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_match_baselines_two_ranks_share_queues_and_banks():
+    import tempfile
+    from test_gpu_dp import _run_pair
+    with tempfile.TemporaryDirectory() as td:
+        r0, r1 = _run_pair(_dp_worker, td)
+    for kind in ("comatch", "simmatch"):
+        a, b = r0[kind], r1[kind]
+        n = a["nb"][0]
+        assert torch.equal(a["params"][:n], b["params"][:n]), kind + ": parameters diverged"
+        for k in a["state"]:
+            assert torch.equal(a["state"][k], b["state"][k]), (kind, k)       # every rank holds the gathered queue / bank
+    co = r0["comatch"]["state"]
+    assert int(co["model.queue_ptr_s"]) == 28 and int(co["model.queue_ptr_w"]) == 32      # 2 x 14 strong / 2 x 16 weak features enqueued
+    assert float(co["model.probs_xu"][:, :32].sum(0).sub(1).abs().max()) < 1e-5 and float(co["model.probs_xu"][:, 32:].abs().max()) == 0.0
+    assert torch.equal(r0["comatch"]["hist"], r1["comatch"]["hist"])                     # all-reduced batch mean of the weak probabilities
+    si = r0["simmatch"]["state"]
+    g = torch.Generator().manual_seed(0)
+    assert float(si["model.bank"][:, [3, 4, 20, 21]].norm(dim=0).sub(1).abs().max()) < 1e-5
+    assert not torch.equal(si["model.bank"][:, 3], si["model.bank"][:, 4])
+    assert int(si["model.DA_ptr"]) == 1
