@@ -217,6 +217,17 @@ int stil_contrast_graph(const float* S, int lds, const float* Q, int ldq, float 
  * c_smooth >= 1. */
 int stil_simmatch_unfold(const float* tpo, const float* probs, const long long* labels, float* teacher, float* pseudo,
                          int rows, int N, int K, float c_smooth, void* stream);
+/* FreeMatch (models/MatchModel/FreeMatchFolder/freematch_model.py:132-168): self-adaptive threshold state update + masking from
+ * probs [rows, K] = softmax of the teacher's weak-view logits: time_p [1], p_model [K], label_hist [K] are updated in place
+ * (EMA with `momentum`), mask[r] = max prob >= time_p * p_model[argmax] / max(p_model), onehot [rows, K] / idx [rows] = the hard
+ * pseudo-labels.  scratch: rows floats. */
+int stil_freematch_update(const float* probs, int rows, int K, float* p_model, float* label_hist, float* time_p,
+                          float momentum, float* mask, float* onehot, int* idx, float* scratch, void* stream);
+/* FreeMatch fairness loss (FreeMatchFolder/freematch_utils.py:18-47) over the rows with mask != 0 of the student's strong-view
+ * logits [rows, K]: loss [1] and dlogits [rows, K] = d loss / d logits (zero outside the mask; both zero when the mask is empty).
+ * Scratch: P [rows, K] floats, pred [rows] ints, vec [4 K] floats. */
+int stil_freematch_entropy(const float* logits, const float* mask, int rows, int K, const float* p_model,
+                           const float* label_hist, float* loss, float* dlogits, float* P, int* pred, float* vec, void* stream);
 /* logged partition ratios (STiLModel.py:307-311) from cgpl_pgls's flags [rows,ld] = (case id 1..4, mask1, ...):
  * out5 = {threshold1_ratio, case1_ratio, case2_i_ratio, case2_t_ratio, case3_ratio} */
 int stil_flag_ratios(const unsigned char* flags, int ld, int rows, float* out5, void* stream);

@@ -34,18 +34,34 @@ CASES = {
     "simmatch_r18_e0": ("simmatch", dict(R18, K=30), 0, 16, None),
     "simmatch_r18_bank": ("simmatch", dict(R18, K=30), 2, 16, dict(da_rows=5)),
     "simmatch_r18_img_noDA": ("simmatch", dict(R18, K=12, num_classes=2, eval_datatype="imaging", DA=False, c_smooth=1.0), 1, 16, dict(da_rows=0)),
+    "freematch_r18_e0": ("freematch", dict(R18, lambda_u=1.0), 0, 16, None),
+    "freematch_r18_mask": ("freematch", dict(R18, lambda_u=1.0, lambda_e=0.5), 2, 16, dict(seed=5)),
+    "freematch_r18_img_binary": ("freematch", dict(R18, lambda_u=1.0, lambda_e=0.5, num_classes=2, eval_datatype="imaging"), 1, 16, dict(seed=6)),
 }
 OUT = {"comatch": (["loss", "loss_x", "loss_u", "loss_contrast"], ["outputs_x", "outputs_u_s0", "probs", "mask", "Q", "sim"]),
-       "simmatch": (["loss", "loss_x", "loss_u", "loss_in"], ["logits_x", "logits_u_s", "pseudo_label", "mask"])}
-LOCALS = {"comatch": ["loss_x", "loss_u", "loss_contrast", "mask"], "simmatch": ["loss_x", "loss_u", "loss_in", "mask"]}
-STUDENT = {"comatch": "model.encoder.", "simmatch": "model.main."}
+       "simmatch": (["loss", "loss_x", "loss_u", "loss_in"], ["logits_x", "logits_u_s", "pseudo_label", "mask"]),
+       "freematch": (["loss", "sup_loss", "unsup_loss", "ent_loss"], ["logits_x_lb", "logits_x_ulb_s", "pseudo_label", "mask", "p_model", "label_hist", "time_p"])}
+LOCALS = {"comatch": ["loss_x", "loss_u", "loss_contrast", "mask"], "simmatch": ["loss_x", "loss_u", "loss_in", "mask"],
+          "freematch": ["sup_loss", "unsup_loss", "ent_loss", "mask"]}
+STUDENT = {"comatch": "model.encoder.", "simmatch": "model.main.", "freematch": "model.main."}
+INIT = {"comatch": MO.comatch_init_state, "simmatch": MO.simmatch_init_state, "freematch": MO.freematch_init_state}
+STEP = {"comatch": MO.comatch_training_step, "simmatch": MO.simmatch_training_step, "freematch": MO.freematch_training_step}
+
+
+def clone_aux(aux, dtype=None):
+    out = {}
+    for k, v in aux.items():
+        if isinstance(v, list):
+            out[k] = [t.clone() if dtype is None else t.to(dtype) for t in v]
+        else:
+            out[k] = v.clone() if dtype is None else v.to(dtype)
+    return out
 
 
 def build_case(name):
     kind, over, epoch, B, preset = CASES[name]
     hp = MO.default_hparams(**over)
-    init = MO.comatch_init_state if kind == "comatch" else MO.simmatch_init_state
-    sd = init(hp, seed=11)
+    sd = INIT[kind](hp, seed=11)
     g = torch.Generator().manual_seed(12)
     stu, tea = STUDENT[kind], ("model.m_encoder." if kind == "comatch" else "model.ema.")
     for k in list(sd.keys()):                        # non-trivial BN statistics / affine parameters, a teacher that lags a little
@@ -82,10 +98,22 @@ def build_case(name):
             sd["model.DA_queue"][:n] = torch.softmax(torch.randn(n, K, generator=g), dim=1)
             sd["model.DA_ptr"] = torch.tensor([n])
     batch = MO.synthetic_batch(hp, B, seed=51, views=3 if kind == "comatch" else 2)
+    if kind == "freematch":
+        aux.update(MO.freematch_aux(hp))
+        if preset:   # a class-probability model / label histogram away from uniform; time_p is set below
+            g2 = torch.Generator().manual_seed(preset["seed"])
+            aux["p_model"] = torch.softmax(torch.randn(K, generator=g2), dim=0)
+            aux["label_hist"] = torch.softmax(torch.randn(K, generator=g2), dim=0)
     # thresholds at the median of a dry run, so that the confidence mask / the pseudo-label graph are mixed
-    dry_fn = MO.comatch_training_step if kind == "comatch" else MO.simmatch_training_step
-    dry = dry_fn({k: v.clone() for k, v in sd.items()}, batch, hp, epoch, {"hist_prob": list(aux.get("hist_prob", []))})
-    if kind == "comatch":
+    dry = STEP[kind]({k: v.clone() for k, v in sd.items()}, batch, hp, epoch, clone_aux(aux))
+    if kind == "freematch":
+        if preset:
+            with torch.no_grad():
+                lw = MO.encoder_forward({k: v.clone() for k, v in sd.items()}, "model.ema.", batch["u"][0][0], hp, train=False)[0]
+            mp_, mi_ = torch.softmax(lw, dim=-1).max(dim=-1)
+            mod = dry["p_model"] / dry["p_model"].max()
+            aux["time_p"] = (mp_ / mod[mi_]).median() - 1e-3
+    elif kind == "comatch":
         hp.co_threshold = float(dry["probs"].max(dim=1).values.median()) - 1e-4
         Qm = dry["Q"]
         off = Qm[~torch.eye(Qm.shape[0], Qm.shape[1], dtype=torch.bool)]
@@ -98,8 +126,10 @@ def build_case(name):
 def run_reference(kind, hp, sd, batch, epoch, aux):
     if kind == "comatch":
         from models.MatchModel.CoMatch import CoMatch as Ref
-    else:
+    elif kind == "simmatch":
         from models.MatchModel.SimMatch import SimMatch as Ref
+    else:
+        from models.MatchModel.FreeMatchFolder.FreeMatch import FreeMatch as Ref
     with tempfile.TemporaryDirectory() as td:
         fl = os.path.join(td, "fl.pt")
         torch.save(list(hp.field_lengths), fl)
@@ -112,6 +142,8 @@ def run_reference(kind, hp, sd, batch, epoch, aux):
     model.model.use_ddp = False
     if kind == "comatch":
         model.model.hist_prob = [t.clone() for t in aux.get("hist_prob", [])]
+    if kind == "freematch":
+        model.model.p_model, model.model.label_hist, model.model.time_p = aux["p_model"].clone(), aux["label_hist"].clone(), aux["time_p"].clone()
     cap = {}
     fwd = model.model.forward
 
@@ -133,7 +165,7 @@ def run_reference(kind, hp, sd, batch, epoch, aux):
     def prof(frame, event, arg):
         if event == "return" and frame.f_code is step_code:
             for nm in LOCALS[kind]:
-                cap["loc_" + nm] = frame.f_locals[nm].detach().clone()
+                cap["loc_" + nm] = torch.as_tensor(frame.f_locals[nm]).detach().clone()
 
     sys.setprofile(prof)
     try:
@@ -150,8 +182,11 @@ def run_reference(kind, hp, sd, batch, epoch, aux):
     o = cap["out"]
     if kind == "comatch":
         out.update(outputs_x=o[0].detach(), outputs_u_s0=o[1].detach(), probs=o[3].detach(), Q=o[4].detach(), sim=o[5].detach())
-    else:
+    elif kind == "simmatch":
         out.update(logits_x=o[0].detach(), pseudo_label=o[1].detach(), logits_u_s=o[2].detach())
+    else:
+        out.update(logits_x_lb=o[0].detach(), pseudo_label=o[1].detach(), logits_x_ulb_s=o[2].detach(), p_model=model.model.p_model.clone(),
+                   label_hist=model.model.label_hist.clone(), time_p=model.model.time_p.clone())
     state = {k: v.detach().clone() for k, v in model.state_dict().items()}
     hist = [t.clone() for t in model.model.hist_prob] if kind == "comatch" else None
     model.model.forward = fwd
@@ -179,7 +214,7 @@ def main():
         kind, hp, sd, batch, epoch, aux = build_case(name)
         ref_out, ref_grads, ref_state, ref_hist = run_reference(kind, hp, {k: v.clone() for k, v in sd.items()}, batch, epoch, aux)
         sd_o = {k: v.clone() for k, v in sd.items()}
-        aux_o = {"hist_prob": [t.clone() for t in aux.get("hist_prob", [])]}
+        aux_o = clone_aux(aux)
         o = MO.full_step(kind, sd_o, {}, 1, batch, hp, epoch, aux=aux_o)
         o["val_loss"] = torch.nn.functional.cross_entropy(MO.eval_logits(kind, sd_o, batch["l"][0], hp), batch["l"][1])
         bad = []
@@ -207,12 +242,13 @@ def main():
         sd64 = {k: d64(v.clone()) for k, v in sd.items()}
         cv = lambda x: tuple(d64(t) for t in x) if isinstance(x, (tuple, list)) else d64(x)  # noqa: E731
         b64 = {"l": (cv(batch["l"][0]), batch["l"][1], batch["l"][2]), "u": ([cv(v) for v in batch["u"][0]], batch["u"][1])}
-        aux64 = {"hist_prob": [t.double() for t in aux.get("hist_prob", [])]}
-        o64 = MO.full_step(kind, sd64, {}, 1, b64, hp, epoch, aux=aux64)
+        o64 = MO.full_step(kind, sd64, {}, 1, b64, hp, epoch, aux=clone_aux(aux, torch.float64))
         scalars, tensors = OUT[kind]
         fx = {"meta_epoch": np.int64(epoch)}
         for nm in ("co_threshold", "contrast_th", "sim_threshold"):
             fx["meta_" + nm] = np.float64(getattr(hp, nm))
+        if kind == "freematch":
+            fx["meta_time_p"] = aux["time_p"].numpy()
         for k in scalars + ["val_loss"]:
             fx["out_" + k] = ref_out[k].numpy().astype(np.float64)
         for k in tensors:

@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE ONLY -- CPU restatement (functional PyTorch) of the CoMatch and SimMatch baselines of the reference
 (SURVEY.md 8f rank 4): `models/MatchModel/CoMatch.py` + `comatch_model.py`, `models/MatchModel/SimMatch.py` +
-`simmatch_model.py`, both on `models/MatchModel/multimodal_backbone.py` (eval_datatype imaging_and_tabular) or on the
+`simmatch_model.py`, `models/MatchModel/FreeMatchFolder/*.py`, all on `models/MatchModel/multimodal_backbone.py` (eval_datatype imaging_and_tabular) or on the
 image-only `ResNet` wrapper of the two model files (eval_datatype imaging).
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import anything under oracle/.
 
@@ -9,6 +9,7 @@ reference module's state_dict():
   CoMatch : model.queue_s [Dp,Q], model.queue_ptr_s [1], model.probs_u [K,Q], model.queue_w [Dp,Q], model.queue_ptr_w [1],
             model.probs_xu [K,Q], model.encoder.*, model.m_encoder.*
   SimMatch: model.bank [Dp,N_l], model.labels [N_l], (model.DA_queue [256,K], model.DA_ptr [1] when DA), model.main.*, model.ema.*
+  FreeMatch: model.main.*, model.ema.*   (p_model / label_hist / time_p are plain module attributes: `aux`)
   encoder (multimodal): encoder_imaging.*, encoder_tabular.*, image_proj.*, head.0.*, head.2.*, classifier_multimodal.*
   encoder (imaging)   : backbone.*, classifier.*, head.0.*, head.2.*
 CoMatch's distribution-alignment history (`hist_prob`, a Python list on the module, comatch_model.py:94) is not part of
@@ -46,6 +47,7 @@ def default_hparams(**over):
     hp.sim_threshold = 0.9
     hp.lambda_u = 10.0
     hp.lambda_in = 5.0
+    hp.lambda_e = 0.001            # FreeMatch (configs/config_dvm_MultiFreeMatch.yaml:140-143; lambda_u 1.0 there)
     for k, v in over.items():
         setattr(hp, k, v)
     return hp
@@ -262,10 +264,84 @@ def simmatch_training_step(sd, batch, hp, current_epoch: int, aux=None) -> Dict[
                 pseudo_label=prob_ku, prob_ku_orig=prob_ku_orig, teacher_prob=teacher_prob, mask=mask)
 
 
+# ------------------------------------------------------------------------------------------------------------------ FreeMatch
+def freematch_init_state(hp, seed: int = 0) -> Dict[str, Tensor]:
+    """FreeMatchModel (freematch_model.py:39-100): main / ema encoders only; p_model, label_hist and time_p are plain
+    attributes of the module (not in its state_dict) and travel in `aux`."""
+    gen = torch.Generator().manual_seed(seed)
+    sd: Dict[str, Tensor] = {}
+    enc = init_encoder_state(hp, gen, "model.main.")
+    sd.update(enc)
+    for k, v in enc.items():
+        sd["model.ema." + k[len("model.main."):]] = v.clone()
+    return sd
+
+
+def freematch_aux(hp, dtype=torch.float32):
+    K = hp.num_classes
+    p = torch.ones(K, dtype=dtype) / K                                                 # freematch_model.py:50-52
+    return {"p_model": p.clone(), "label_hist": p.clone(), "time_p": p.mean()}
+
+
+def _inf_to_zero(v):
+    v = v.clone()
+    v[v == float("inf")] = 0.0
+    return v
+
+
+def freematch_entropy_loss(mask, logits_s, p_model, label_hist):
+    """freematch_utils.py:18-47 (returns the loss only)."""
+    logits_s = logits_s[mask.bool()]
+    prob_s = logits_s.softmax(dim=-1)
+    _, pred = torch.max(prob_s, dim=-1)
+    hist_s = torch.bincount(pred, minlength=logits_s.shape[1]).to(logits_s.dtype)
+    hist_s = hist_s / hist_s.sum()
+    mod_p = p_model.reshape(1, -1) * _inf_to_zero(1 / label_hist.reshape(1, -1)).detach()
+    mod_p = mod_p / mod_p.sum(dim=-1, keepdim=True)
+    mod_mean = prob_s.mean(dim=0, keepdim=True) * _inf_to_zero(1 / hist_s).detach()
+    mod_mean = mod_mean / mod_mean.sum(dim=-1, keepdim=True)
+    return (mod_p * torch.log(mod_mean + 1e-12)).sum(dim=1).mean()
+
+
+def freematch_training_step(sd, batch, hp, current_epoch: int, aux: dict) -> Dict[str, Tensor]:
+    """FreeMatch.training_step (FreeMatch.py:76-123) + FreeMatchModel.forward (freematch_model.py:170-206)."""
+    x_l, y_l = batch["l"][0], batch["l"][1]
+    u_w, u_s = batch["u"][0][0], batch["u"][0][1]
+    bx, bu = _rows(x_l, hp), _rows(u_w, hp)
+    mm = 0.999                                                                         # self.m (freematch_model.py:48)
+    logits_q, _ = encoder_forward(sd, "model.main.", _cat([x_l, u_s], hp), hp, train=True)
+    logits_x_lb, logits_x_ulb_s = logits_q[:bx], logits_q[bx:]
+    with torch.no_grad():
+        m = hp.ema_momentum
+        for k in list(sd.keys()):                                                      # momentum_update_ema (:113-121)
+            if not k.startswith("model.main."):
+                continue
+            ke = "model.ema." + k[len("model.main."):]
+            sd[ke] = sd[k].clone() if k.endswith("num_batches_tracked") else sd[ke] * m + (1.0 - m) * sd[k].detach()
+        logits_w, _ = encoder_forward(sd, "model.ema.", u_w, hp, train=False)          # weak unlabelled views only
+        probs = torch.softmax(logits_w, dim=-1)
+        max_probs, max_idx = probs.max(dim=-1)                                         # update (:132-147)
+        aux["time_p"] = aux["time_p"] * mm + (1 - mm) * max_probs.mean()
+        aux["p_model"] = aux["p_model"] * mm + (1 - mm) * probs.mean(dim=0)
+        hist = torch.bincount(max_idx, minlength=hp.num_classes).to(probs.dtype)
+        aux["label_hist"] = aux["label_hist"] * mm + (1 - mm) * (hist / hist.sum())
+        mod = aux["p_model"] / torch.max(aux["p_model"], dim=-1)[0]                    # masking (:165-167)
+        mask = max_probs.ge(aux["time_p"] * mod[max_idx]).to(max_probs.dtype)
+        pseudo_label = torch.zeros_like(logits_w)
+        pseudo_label[torch.arange(bu), max_idx] = 1
+    ent_loss = freematch_entropy_loss(mask, logits_x_ulb_s, aux["p_model"], aux["label_hist"]) if mask.sum() > 0 else logits_q.new_zeros(())
+    sup_loss = F.cross_entropy(logits_x_lb, y_l)
+    unsup_loss = F.cross_entropy(logits_x_ulb_s, pseudo_label)                         # every unlabelled sample (the mask is not applied)
+    loss = sup_loss if current_epoch <= hp.start_epoch else sup_loss + hp.lambda_u * unsup_loss + hp.lambda_e * ent_loss
+    return dict(loss=loss, sup_loss=sup_loss, unsup_loss=unsup_loss, ent_loss=ent_loss, logits_x_lb=logits_x_lb, logits_x_ulb_s=logits_x_ulb_s,
+                pseudo_label=pseudo_label, mask=mask, p_model=aux["p_model"], label_hist=aux["label_hist"], time_p=aux["time_p"])
+
+
 # ------------------------------------------------------------------------------------------------------------------ drivers
 def full_step(kind: str, sd, opt, step_idx, batch, hp, current_epoch, aux=None, lr=None):
     """zero_grad -> training_step -> backward -> Adam on the student's parameters."""
-    step_fn, student = (comatch_training_step, "model.encoder.") if kind == "comatch" else (simmatch_training_step, "model.main.")
+    step_fn, student = {"comatch": (comatch_training_step, "model.encoder."), "simmatch": (simmatch_training_step, "model.main."),
+                        "freematch": (freematch_training_step, "model.main.")}[kind]
     keys = trainable_keys(sd, student)
     for k in keys:
         sd[k].requires_grad_(True)

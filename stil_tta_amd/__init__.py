@@ -5,7 +5,7 @@ Importing the package does not need a GPU; running any operator does (there is n
 from ._lib import lib, build, LIB_PATH  # noqa: F401
 from .stil_model import STiLModel  # noqa: F401
 from .mmatch import CoTraining, MMatch  # noqa: F401
-from .match import CoMatch, SimMatch  # noqa: F401
+from .match import CoMatch, FreeMatch, SimMatch  # noqa: F401
 
 
 
@@ -19,4 +19,4 @@ class SemiDisCoPseudoSmooth(STiLModel):
         super().__init__(hp)
 
 
-__all__ = ["STiLModel", "SemiDisCoPseudoSmooth", "MMatch", "CoTraining", "CoMatch", "SimMatch", "lib", "build", "LIB_PATH"]
+__all__ = ["STiLModel", "SemiDisCoPseudoSmooth", "MMatch", "CoTraining", "CoMatch", "SimMatch", "FreeMatch", "lib", "build", "LIB_PATH"]

@@ -642,6 +642,143 @@ extern "C" int stil_simmatch_unfold(const float* tpo, const float* probs, const 
   return STIL_OK;
 }
 
+// FreeMatch self-adaptive thresholding (models/MatchModel/FreeMatchFolder/freematch_model.py:132-168), one workgroup:
+//   time_p <- m time_p + (1-m) mean_r max_k probs;  p_model <- m p_model + (1-m) mean_r probs;  label_hist <- m label_hist +
+//   (1-m) bincount(argmax)/R;  mask[r] = max_k probs[r] >= time_p * p_model[idx_r] / max(p_model);  onehot[r] = e_idx_r.
+// scratch: R floats.  Fixed-order sums.
+__global__ __launch_bounds__(256) void freematch_update_kernel(const float* __restrict__ probs, int R, int K, float* __restrict__ p_model,
+                                                                float* __restrict__ label_hist, float* __restrict__ time_p, float m,
+                                                                float* __restrict__ mask, float* __restrict__ onehot, int* __restrict__ idx,
+                                                                float* __restrict__ scratch) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int r = threadIdx.x; r < R; r += 256) {
+    const float* pr = probs + (long)r * K;
+    float best = pr[0];
+    int bi = 0;
+    for (int k = 1; k < K; ++k)
+      if (pr[k] > best) { best = pr[k]; bi = k; }
+    scratch[r] = best;
+    idx[r] = bi;
+    s += best;
+    for (int k = 0; k < K; ++k) onehot[(long)r * K + k] = k == bi ? 1.f : 0.f;
+  }
+  s = block_sum(s, red);      // (block_sum ends with a barrier: scratch / idx are visible to the whole workgroup)
+  const float tp = time_p[0] * m + (1.f - m) * (s / (float)R);
+  float pmax = -INFINITY;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    float cs = 0.f, cnt = 0.f;
+    for (int r = 0; r < R; ++r) { cs += probs[(long)r * K + k]; cnt += idx[r] == k ? 1.f : 0.f; }
+    const float pm = p_model[k] * m + (1.f - m) * (cs / (float)R);
+    p_model[k] = pm;
+    label_hist[k] = label_hist[k] * m + (1.f - m) * (cnt / (float)R);
+    pmax = fmaxf(pmax, pm);
+  }
+  pmax = block_max(pmax, red);
+  __syncthreads();
+  if (threadIdx.x == 0) time_p[0] = tp;
+  for (int r = threadIdx.x; r < R; r += 256) mask[r] = scratch[r] >= tp * (p_model[idx[r]] / pmax) ? 1.f : 0.f;
+}
+
+extern "C" int stil_freematch_update(const float* probs, int rows, int K, float* p_model, float* label_hist, float* time_p,
+                                     float momentum, float* mask, float* onehot, int* idx, float* scratch, void* stream) {
+  STIL_REQUIRE(probs && p_model && label_hist && time_p && mask && onehot && idx && scratch && rows > 0 && K > 0,
+               "stil_freematch_update: bad arguments");
+  hipLaunchKernelGGL(freematch_update_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, probs, rows, K, p_model, label_hist, time_p,
+                     momentum, mask, onehot, idx, scratch);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+// FreeMatch fairness ("entropy") loss (freematch_utils.py:18-47) over the rows with mask != 0, one workgroup:
+//   a = normalise(p_model * inf0(1/label_hist));  hist = bincount(argmax softmax(z))/n;  v = mean_r softmax(z) * inf0(1/hist);
+//   loss = sum_k a_k log(v_k / sum(v) + 1e-12);  dz = d loss / d z (rows outside the mask: 0);  n == 0: loss = 0, dz = 0.
+// P: [R,K] scratch (the softmax rows);  vec: 4*K floats of scratch.
+__global__ __launch_bounds__(256) void freematch_entropy_kernel(const float* __restrict__ z, const float* __restrict__ mask, int R, int K,
+                                                                 const float* __restrict__ p_model, const float* __restrict__ label_hist,
+                                                                 float* __restrict__ loss, float* __restrict__ dz, float* __restrict__ P,
+                                                                 int* __restrict__ pred, float* __restrict__ vec) {
+  __shared__ float red[16];
+  float* a = vec;            // modulated prob model
+  float* sc = vec + K;       // inf0(1 / hist_s)
+  float* mmv = vec + 2 * K;  // modulated mean prob
+  float* dmean = vec + 3 * K;
+  float n = 0.f;
+  for (int r = threadIdx.x; r < R; r += 256) {
+    const bool on = mask[r] != 0.f;
+    n += on ? 1.f : 0.f;
+    const float* zr = z + (long)r * K;
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) mx = fmaxf(mx, zr[k]);
+    float se = 0.f;
+    for (int k = 0; k < K; ++k) se += expf(zr[k] - mx);
+    float best = -1.f;
+    int bi = 0;
+    for (int k = 0; k < K; ++k) {
+      const float p = expf(zr[k] - mx) / se;
+      P[(long)r * K + k] = p;
+      if (p > best) { best = p; bi = k; }
+    }
+    pred[r] = on ? bi : -1;
+  }
+  n = block_sum(n, red);
+  if (n == 0.f) {
+    if (threadIdx.x == 0) loss[0] = 0.f;
+    for (long i = threadIdx.x; i < (long)R * K; i += 256) dz[i] = 0.f;
+    return;
+  }
+  float asum = 0.f, vsum = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    float cnt = 0.f, cs = 0.f;
+    for (int r = 0; r < R; ++r)
+      if (pred[r] >= 0) { cnt += pred[r] == k ? 1.f : 0.f; cs += P[(long)r * K + k]; }
+    const float h = cnt / n, lh = label_hist[k];
+    const float s1 = 1.f / lh, s2 = 1.f / h;
+    a[k] = p_model[k] * (isinf(s1) ? 0.f : s1);
+    sc[k] = isinf(s2) ? 0.f : s2;
+    mmv[k] = (cs / n) * sc[k];
+    asum += a[k];
+    vsum += mmv[k];
+  }
+  asum = block_sum(asum, red);
+  vsum = block_sum(vsum, red);
+  float l = 0.f, bs = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float ak = a[k] / asum, mk = mmv[k] / vsum;
+    const float b = ak / (mk + 1e-12f);
+    l += ak * logf(mk + 1e-12f);
+    bs += b * mk;
+    a[k] = b;
+  }
+  l = block_sum(l, red);
+  bs = block_sum(bs, red);
+  if (threadIdx.x == 0) loss[0] = l;
+  for (int k = threadIdx.x; k < K; k += 256) dmean[k] = sc[k] * (a[k] - bs) / vsum;
+  __syncthreads();
+  for (int r = threadIdx.x; r < R; r += 256) {
+    float* dr = dz + (long)r * K;
+    if (pred[r] < 0) {
+      for (int k = 0; k < K; ++k) dr[k] = 0.f;
+      continue;
+    }
+    const float* pr = P + (long)r * K;
+    float dot = 0.f;
+    for (int k = 0; k < K; ++k) dot += pr[k] * dmean[k];
+    for (int k = 0; k < K; ++k) dr[k] = pr[k] * (dmean[k] - dot) / n;
+  }
+}
+
+extern "C" int stil_freematch_entropy(const float* logits, const float* mask, int rows, int K, const float* p_model,
+                                      const float* label_hist, float* loss, float* dlogits, float* P, int* pred, float* vec,
+                                      void* stream) {
+  STIL_REQUIRE(logits && mask && p_model && label_hist && loss && dlogits && P && pred && vec && rows > 0 && K > 0,
+               "stil_freematch_entropy: bad arguments");
+  hipLaunchKernelGGL(freematch_entropy_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, mask, rows, K, p_model, label_hist,
+                     loss, dlogits, P, pred, vec);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
 // ---- logged partition ratios (STiLModel.py:307-311): out = {mean(mask1), mean(case == 1), .. == 2, .. == 3, .. == 4}
 // flags: [rows, ld] bytes, columns (CGPL case id 1..4, mask1, ...) as written by cgpl_pgls_kernel.  One block, fixed order.
 __global__ __launch_bounds__(256) void flag_ratios_kernel(const unsigned char* __restrict__ flags, int ld, int rows, float* __restrict__ out) {

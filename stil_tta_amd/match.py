@@ -1,5 +1,5 @@
-"""CoMatch and SimMatch baselines on the same HIP kernels: `models/MatchModel/CoMatch.py` +
-`comatch_model.py`, `models/MatchModel/SimMatch.py` + `simmatch_model.py` and their encoder
+"""CoMatch, SimMatch and FreeMatch baselines on the same HIP kernels: `models/MatchModel/CoMatch.py` +
+`comatch_model.py`, `models/MatchModel/SimMatch.py` + `simmatch_model.py`, `models/MatchModel/FreeMatchFolder/*.py` and their encoder
 `models/MatchModel/multimodal_backbone.py` (or the image-only `ResNet` wrapper for eval_datatype == 'imaging') of the
 reference: same class names, constructor, hooks and `state_dict` keys (asserted against the reference when the golden
 vectors tests/golden/comatch_*.npz, simmatch_*.npz are generated).
@@ -7,7 +7,8 @@ vectors tests/golden/comatch_*.npz, simmatch_*.npz are generated).
 Batch layout (trainers/evaluate.py:50-83): batch['l'] = (x, y, index), batch['u'] = ((weak, strong[, strong2]), y_u) with
 x = (image, table) or image.  Both steps run the student on [labelled ; strong] and a momentum copy of it on the weak
 views; CoMatch keeps two feature/probability queues and builds a pseudo-label graph for a graph-contrastive loss, SimMatch
-keeps a labelled memory bank and matches the student's similarity distribution to the teacher's.  There is no CPU path.
+keeps a labelled memory bank and matches the student's similarity distribution to the teacher's, FreeMatch adapts its
+confidence threshold per class from running statistics of the teacher's predictions.  There is no CPU path.
 """
 from __future__ import annotations
 
@@ -418,4 +419,67 @@ class SimMatch(_MatchBase):
             self._train_metrics(logits_qx, y_l, logits_qu, y_u)
         self.last = dict(loss=loss, loss_x=loss_x, loss_u=loss_u, loss_in=loss_in, logits_x=logits_qx, logits_u_s=logits_qu, feat_qu=feat_qu,
                          pseudo_label=prob_ku, prob_ku_orig=prob_ku_orig, teacher_prob=teacher_prob, mask=mask)
+        return loss
+
+
+# ====================================================================================================================== FreeMatch
+class FreeMatchModel(nn.Module):
+    """FreeMatchFolder/freematch_model.py:39-100: main / ema encoders; the self-adaptive threshold state (p_model, label_hist,
+    time_p) is a set of plain attributes on the reference module -- here non-persistent buffers, absent from the state_dict too."""
+
+    def __init__(self, hp, field_lengths):
+        super().__init__()
+        K = hp.num_classes
+        self.main = MatchBackbone(hp, field_lengths)
+        self.ema = MatchBackbone(hp, field_lengths)
+        self.ema.load_state_dict(self.main.state_dict())
+        for q in self.ema.parameters():
+            q.requires_grad = False
+        self.m = 0.999
+        self.register_buffer("p_model", torch.ones(K) / K, persistent=False)
+        self.register_buffer("label_hist", torch.ones(K) / K, persistent=False)
+        self.register_buffer("time_p", (torch.ones(K) / K).mean().reshape(1), persistent=False)
+
+
+class FreeMatch(_MatchBase):
+    STUDENT, TEACHER = "main", "ema"
+
+    def __init__(self, hparams):  # noqa: D401 -- not STiLModel.__init__
+        hp = self._init_common(hparams, dict(lambda_u=1.0, lambda_e=0.001, eval_datatype="imaging_and_tabular"))
+        self.model = FreeMatchModel(hp, self.field_lengths)
+        self.initialize_metrics(hp.num_classes, hp.num_classes)
+
+    def training_step(self, batch, _=None):
+        hp, M = self.hp, self.model
+        self.setup_device()
+        dev = self.prototypes.device
+        x_l, y_l = batch["l"][0], batch["l"][1].to(dev)
+        (u_w, u_s), y_u = batch["u"][0], batch["u"][1].to(dev)
+        bx, bu = self._rows(x_l), self._rows(u_w)
+        epoch = self.current_epoch
+        logits_q, _ = M.main.run(self._cat([x_l, u_s], dev), True)                                 # freematch_model.py:182-186
+        logits_x_lb, logits_x_ulb_s = logits_q[:bx].contiguous(), logits_q[bx:].contiguous()
+        with torch.no_grad():
+            self.flat.ema_update(hp.ema_momentum, True)                                             # whole state_dict (:113-121)
+            logits_w, _ = M.ema.run(self._to_dev(u_w, dev), False)                                  # weak unlabelled views only (:191)
+            probs = _gather_rows(ops.softmax_rows(logits_w.contiguous()))                           # update() sees every rank's rows (:133-134)
+            mask, pseudo_label, _ = ops.freematch_update(probs, M.p_model, M.label_hist, M.time_p, M.m)
+            if _world() > 1:
+                r0 = dist.get_rank() * bu
+                mask, pseudo_label = mask[r0:r0 + bu].contiguous(), pseudo_label[r0:r0 + bu].contiguous()
+            ones = torch.ones((bu,), dtype=torch.float32, device=dev)
+        ent_loss = ops.FreeMatchEntropyFn.apply(logits_x_ulb_s, mask, M.p_model, M.label_hist)      # 0 when nothing passes (:199-202)
+        sup_loss = ops.CEHardFn.apply(logits_x_lb, y_l)
+        unsup_loss = ops.CESoftFn.apply(logits_x_ulb_s, pseudo_label, ones)                         # every sample: the mask is not applied (FreeMatch.py:92)
+        loss = sup_loss if epoch <= hp.start_epoch else sup_loss + hp.lambda_u * unsup_loss + hp.lambda_e * ent_loss
+        bs = bx + bu
+        self.log("multimodal.train.loss", loss.detach(), on_epoch=True, on_step=False, batch_size=bs)
+        ratio = torch.empty((), dtype=torch.float32, device=dev)
+        lib().reduce_sum(_p(mask), bu, 1.0 / bu, _p(ratio), 0, _stream())
+        self.log("multimodal.train.threshold1_ratio", ratio, on_epoch=True, on_step=False, batch_size=bs)
+        with torch.no_grad():
+            self._train_metrics(logits_x_lb, y_l, logits_x_ulb_s, y_u)
+        self.last = dict(loss=loss, sup_loss=sup_loss, unsup_loss=unsup_loss, ent_loss=ent_loss, logits_x_lb=logits_x_lb,
+                         logits_x_ulb_s=logits_x_ulb_s, pseudo_label=pseudo_label, mask=mask, p_model=M.p_model, label_hist=M.label_hist,
+                         time_p=M.time_p)
         return loss

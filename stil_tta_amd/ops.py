@@ -831,6 +831,44 @@ def simmatch_unfold(tpo, probs, labels, c_smooth):
     return teacher, pseudo
 
 
+def freematch_update(probs, p_model, label_hist, time_p, momentum=0.999):
+    """Self-adaptive threshold state (updated in place) -> mask [R], one-hot pseudo-labels [R,K], argmax [R]
+    (FreeMatchFolder/freematch_model.py:132-168); no gradient."""
+    _chk(probs, p_model, label_hist, time_p)
+    R, K = probs.shape
+    dev = probs.device
+    mask = torch.empty((R,), dtype=torch.float32, device=dev)
+    onehot = torch.empty((R, K), dtype=torch.float32, device=dev)
+    idx = torch.empty((R,), dtype=torch.int32, device=dev)
+    scratch = torch.empty((R,), dtype=torch.float32, device=dev)
+    lib().freematch_update(_p(probs), R, K, _p(p_model), _p(label_hist), _p(time_p), float(momentum), _p(mask), _p(onehot), _p(idx),
+                           _p(scratch), _stream())
+    return mask, onehot, idx
+
+
+class FreeMatchEntropyFn(torch.autograd.Function):
+    """FreeMatch's fairness loss over the masked rows (FreeMatchFolder/freematch_utils.py:18-47); 0 when the mask is empty."""
+
+    @staticmethod
+    def forward(ctx, logits, mask, p_model, label_hist):
+        _chk(logits, mask, p_model, label_hist)
+        R, K = logits.shape
+        dev = logits.device
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        dz = torch.empty_like(logits)
+        P = torch.empty_like(logits)
+        pred = torch.empty((R,), dtype=torch.int32, device=dev)
+        vec = torch.empty((4 * K,), dtype=torch.float32, device=dev)
+        lib().freematch_entropy(_p(logits), _p(mask), R, K, _p(p_model), _p(label_hist), _p(loss), _p(dz), _p(P), _p(pred), _p(vec), _stream())
+        ctx.save_for_backward(dz)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dz,) = ctx.saved_tensors
+        return _scale_by(dz, g), None, None, None
+
+
 def clip_loss(f0, f1, T, lam0, gather=False):
     """CLIPLoss.forward (utils/clip_loss.py:27-39). Returns (loss, logits).
     gather (data-parallel `global_contrast`): both embeddings are all-gathered with autograd

@@ -56,12 +56,16 @@ def test_match_training_step_matches_reference_golden(name):
     kind, hp, sd, batch, epoch, aux = GX.build_case(name)
     for nm in ("co_threshold", "contrast_th", "sim_threshold"):   # data-dependent thresholds of the generating machine
         setattr(hp, nm, float(fx["meta_" + nm]))
-    m = (stil_tta_amd.CoMatch if kind == "comatch" else stil_tta_amd.SimMatch)(dict(vars(hp)))
+    if kind == "freematch":
+        aux["time_p"] = torch.tensor(fx["meta_time_p"])
+    m = {"comatch": stil_tta_amd.CoMatch, "simmatch": stil_tta_amd.SimMatch, "freematch": stil_tta_amd.FreeMatch}[kind](dict(vars(hp)))
     assert list(m.state_dict().keys()) == list(sd.keys())
     m.load_state_dict({k: v.clone() for k, v in sd.items()})
     m.setup_device("cuda"); m.train(); m.current_epoch = epoch
     if kind == "comatch":
         m.model.hist_prob = [t.cuda() for t in aux.get("hist_prob", [])]
+    if kind == "freematch":
+        m.model.p_model.copy_(aux["p_model"]); m.model.label_hist.copy_(aux["label_hist"]); m.model.time_p.copy_(aux["time_p"].reshape(1))
     dbatch = {"l": tuple(_dev(t) for t in batch["l"]), "u": (_dev(batch["u"][0]), batch["u"][1].cuda())}
     with _trace_decisions() as tr:
         train_step(m, StilAdam(m.flat, lr=hp.lr_eval), dbatch)
@@ -75,7 +79,7 @@ def test_match_training_step_matches_reference_golden(name):
     if kind == "comatch":
         L["sim"] = torch.exp(L["sim_logits"].detach())
     for k in scalars + tensors:
-        ok, err = _close(L[k].detach().cpu().numpy(), fx["out_" + k])
+        ok, err = _close(L[k].detach().cpu().numpy().reshape(fx["out_" + k].shape), fx["out_" + k])
         if not ok:
             bad.append((k, err))
     assert np.array_equal(L["mask"].cpu().numpy() > 0.5, fx["out_mask"] > 0.5), "confidence mask"
@@ -84,9 +88,8 @@ def test_match_training_step_matches_reference_golden(name):
     cv = lambda x: tuple(d64(t) for t in x) if isinstance(x, (tuple, list)) else d64(x)  # noqa: E731
     sd64 = {k: d64(v.clone()) for k, v in sd.items()}
     b64 = {"l": (cv(batch["l"][0]), batch["l"][1], batch["l"][2]), "u": ([cv(v) for v in batch["u"][0]], batch["u"][1])}
-    aux64 = {"hist_prob": [t.double() for t in aux.get("hist_prob", [])]}
     with O.force_decisions(relu, pool) as dec:
-        o64 = XO.full_step(kind, sd64, {}, 1, b64, hp, epoch, aux=aux64)
+        o64 = XO.full_step(kind, sd64, {}, 1, b64, hp, epoch, aux=GX.clone_aux(aux, torch.float64))
     _check_flips(dec.get("flips", {}))
     params = dict(m.named_parameters())
     gbad, ratios = _grad_errors(params, o64["grads"], lambda k: float(fx["gerr32_" + k]) if ("gerr32_" + k) in fx.files else 0.0)
@@ -116,7 +119,7 @@ def test_match_training_step_matches_reference_golden(name):
     assert not bad, f"{len(bad)} mismatches, first: {bad[:8]}"
     # validation hook on the post-step weights of the REFERENCE (Adam noise excluded): load the oracle's post-step state
     sd_o = {k: v.clone() for k, v in sd.items()}
-    XO.full_step(kind, sd_o, {}, 1, batch, hp, epoch, aux={"hist_prob": [t.clone() for t in aux.get("hist_prob", [])]})
+    XO.full_step(kind, sd_o, {}, 1, batch, hp, epoch, aux=GX.clone_aux(aux))
     m.load_state_dict(sd_o)
     m.eval()
     ok, err = _close(m.validation_step((_dev(batch["l"][0]), batch["l"][1].cuda())).cpu().numpy(), fx["out_val_loss"])

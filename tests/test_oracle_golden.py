@@ -178,6 +178,8 @@ def _match_case(name):
     kind, hp, sd, batch, epoch, aux = GX.build_case(name)
     for nm in ("co_threshold", "contrast_th", "sim_threshold"):   # data-dependent thresholds of the generating machine
         setattr(hp, nm, float(fx["meta_" + nm]))
+    if kind == "freematch":
+        aux["time_p"] = torch.tensor(fx["meta_time_p"])
     return fx, kind, hp, sd, batch, epoch, aux
 
 
@@ -204,13 +206,14 @@ def test_match_oracle_matches_reference_golden(name):
         assert len(aux["hist_prob"]) == int(fx["hist_len"]) and _close(aux["hist_prob"][-1].numpy(), fx["hist_last"], 2e-5)
 
 
-@pytest.mark.parametrize("name", ["comatch_r18_bank", "comatch_r18_img_binary", "simmatch_r18_bank", "simmatch_r18_img_noDA"])
+@pytest.mark.parametrize("name", ["comatch_r18_bank", "comatch_r18_img_binary", "simmatch_r18_bank", "simmatch_r18_img_noDA", "freematch_r18_mask",
+                                  "freematch_r18_img_binary"])
 def test_match_state_dict_layout(name):
     import stil_tta_amd
     kind, over, _, _, _ = GX.CASES[name]
     hp = XO.default_hparams(**over)
-    sd = (XO.comatch_init_state if kind == "comatch" else XO.simmatch_init_state)(hp, seed=0)
-    m = (stil_tta_amd.CoMatch if kind == "comatch" else stil_tta_amd.SimMatch)(dict(vars(hp)))
+    sd = GX.INIT[kind](hp, seed=0)
+    m = {"comatch": stil_tta_amd.CoMatch, "simmatch": stil_tta_amd.SimMatch, "freematch": stil_tta_amd.FreeMatch}[kind](dict(vars(hp)))
     got = m.state_dict()
     assert list(got.keys()) == list(sd.keys())
     assert all(tuple(got[k].shape) == tuple(sd[k].shape) for k in sd)
