@@ -239,6 +239,9 @@ int stil_onehot_argmax(const float* probs, int rows, int K, float threshold, flo
 
 /* ---- flat-slab EMA teacher update and Adam: STiLModel.py:154-168, 563-570 */
 int stil_ema_update(float* ema, const float* model, long n, double momentum, void* stream);
+/* the reference's EMA applied to int64 buffers (CoTraining_SAINT.py:102-105: float32 arithmetic, truncating copy):
+ * ema[i] = (int64)(fl(float(ema[i]) * m) + fl(float(1 - m) * float(model[i]))) */
+int stil_ema_int_trunc(long long* ema, const long long* model, int n, double momentum, void* stream);
 int stil_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                    const int* chunk2tensor, int* steps, const unsigned char* active, int n_tensors, long n,
                    float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,

@@ -216,3 +216,112 @@ def cotrain_full_step(sd, opt, step_idx, batch, hp, current_epoch, lr=None):
     out = {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in out.items()}
     out["grads"] = grads
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CoTraining with SAINT's tabular encoder ("CoTrain_Pseudo_SAINT", models/SemiMultimodal/CoTraining_SAINT.py +
+# Multimodal_model_SAINT.py): the SAINT row/column encoder of STiL_SAINT (embedding 32) replaces the tabular transformer,
+# `tabular_proj` becomes Linear(32, C) and `classifier_tabular` Linear(32, K); state = model.cls_token, model.encoder_imaging.*,
+# model.encoder_tabular.* (SAINT), projections / classifiers [+ ema.*].
+# NB CoTraining_SAINT.momentum_update_ema (eman) applies `v_ema.copy_(v_ema * m + (1 - m) * v_main)` to SAINT's int64
+# *_offset buffers too (only num_batches_tracked is copied, CoTraining_SAINT.py:102-105): the float32 result is truncated
+# back to int64, so the TEACHER's categories_offset entries drift by one for some values (29, 39, 58, ... at m = 0.996).
+# Restated literally: parity is with the reference as shipped.
+# ------------------------------------------------------------------------------------------------------------------
+def cotrain_saint_hparams(**over):
+    hp = cotrain_hparams(tabular_encoder="saint")
+    for k, v in over.items():
+        setattr(hp, k, v)
+    return hp
+
+
+def cotrain_saint_init_state(hp, seed: int = 0) -> Dict[str, Tensor]:
+    gen = torch.Generator().manual_seed(seed)
+    K, Dp, C, Dt = hp.num_classes, hp.projection_dim, hp.multimodal_embedding_dim, O.SAINT_DIM
+    sd: Dict[str, Tensor] = {"model.cls_token": torch.zeros(1, 1)}
+    bb = O.init_backbone_state(hp, gen)
+    for k, v in bb.items():
+        if k.startswith("encoder_imaging."):
+            sd["model." + k] = v
+    for k, v in O.init_saint_state(hp, gen).items():
+        sd["model.encoder_tabular." + k] = v
+    O._linear_init(sd, "model.image_proj", C, hp.embedding_dim, gen)
+    O._linear_init(sd, "model.tabular_proj", C, Dt, gen)
+    O._linear_init(sd, "model.multimodal_proj", Dp, 2 * C, gen)
+    O._linear_init(sd, "model.classifier_multimodal", K, Dp, gen)
+    O._linear_init(sd, "model.classifier_imaging", K, hp.embedding_dim, gen)
+    O._linear_init(sd, "model.classifier_tabular", K, Dt, gen)
+    if hp.use_ema:
+        for k in list(sd.keys()):
+            sd["ema." + k[len("model."):]] = sd[k].clone()
+    return sd
+
+
+def saint_backbone_forward(sd, x_img, x_tab, hp, train: bool, p: str = "model.", masks=None):
+    """MultimodalBackbone.forward of Multimodal_model_SAINT.py:187-195: -> out_m, out_i, out_t, x_m."""
+    x_i = O.resnet_forward(sd, p + "encoder_imaging.", x_img, hp.model, train).mean(dim=(2, 3))
+    x_t = O.saint_tabular_forward(sd, p, x_tab, hp, masks if train else None)
+    cls = x_t[:, 0, :]
+    lin = lambda t, n: F.linear(t, sd[p + n + ".weight"], sd[p + n + ".bias"])  # noqa: E731
+    x_m = lin(torch.cat([lin(x_i, "image_proj"), lin(cls, "tabular_proj")], dim=1), "multimodal_proj")
+    return lin(x_m, "classifier_multimodal"), lin(x_i, "classifier_imaging"), lin(cls, "classifier_tabular"), x_m
+
+
+def cotrain_saint_ema_update(sd, m: float, eman: bool):
+    """CoTraining_SAINT.momentum_update_ema (:95-109), literally (see the note above for the integer buffers)."""
+    with torch.no_grad():
+        for k in list(sd.keys()):
+            if not k.startswith("model."):
+                continue
+            ke = "ema." + k[len("model."):]
+            is_buf = not sd[k].is_floating_point() or k.endswith("running_mean") or k.endswith("running_var")
+            if eman:
+                if "num_batches_tracked" in k:
+                    sd[ke].copy_(sd[k])
+                else:
+                    sd[ke].copy_(sd[ke] * m + (1.0 - m) * sd[k].detach())
+            elif not is_buf:
+                sd[ke] = sd[ke] * m + sd[k].detach() * (1.0 - m)
+
+
+def cotrain_saint_training_step(sd, batch, hp, current_epoch: int, masks=None) -> Dict[str, Tensor]:
+    """CoTraining.training_step of CoTraining_SAINT.py:112-172 (identical to CoTraining.py but for the backbone)."""
+    im_l, tab_l, y_l = batch["l"][0][1], batch["l"][1][1], batch["l"][2]
+    im_u, tab_u = batch["u"][0][1], batch["u"][1][1]
+    B_l = len(y_l)
+    x_img, x_tab = torch.cat((im_l, im_u)), torch.cat((tab_l, tab_u))
+    y_m, y_i, y_t, _ = saint_backbone_forward(sd, x_img, x_tab, hp, train=True, masks=masks)
+    with torch.no_grad():
+        if hp.use_ema:
+            cotrain_saint_ema_update(sd, hp.ema_momentum, hp.eman)
+            ym_e, yi_e, yt_e, _ = saint_backbone_forward(sd, x_img, x_tab, hp, train=False, p="ema.")
+        else:
+            ym_e, yi_e, yt_e = y_m.detach().clone(), y_i.detach().clone(), y_t.detach().clone()
+    ce = F.cross_entropy
+    loss_ce = ce(y_m[:B_l], y_l) + ce(y_i[:B_l], y_l) + ce(y_t[:B_l], y_l)
+    pl_i = torch.softmax(yi_e[B_l:].detach(), dim=1)
+    pl_t = torch.softmax(yt_e[B_l:].detach(), dim=1)
+    mask_i = pl_i.max(dim=1).values.ge(hp.co_threshold)
+    mask_t = pl_t.max(dim=1).values.ge(hp.co_threshold)
+    loss_i_u = (ce(y_i[B_l:], pl_t, reduction="none") * mask_t).mean()
+    loss_t_u = (ce(y_t[B_l:], pl_i, reduction="none") * mask_i).mean()
+    loss = hp.alpha * loss_ce
+    if current_epoch > hp.start_epoch:
+        loss = loss + hp.rate_uce * (loss_i_u + loss_t_u)
+    return dict(loss=loss, loss_ce=loss_ce, loss_i_u=loss_i_u, loss_t_u=loss_t_u, y_hat_m=y_m, y_hat_i=y_i, y_hat_t=y_t,
+                y_hat_i_e=yi_e, y_hat_t_e=yt_e, pseudo_label_i=pl_i, pseudo_label_t=pl_t, mask_i=mask_i, mask_t=mask_t)
+
+
+def cotrain_saint_full_step(sd, opt, step_idx, batch, hp, current_epoch, masks=None, lr=None):
+    keys = [k for k in trainable_keys(sd) if "offset" not in k]
+    for k in keys:
+        sd[k].requires_grad_(True)
+    out = cotrain_saint_training_step(sd, batch, hp, current_epoch, masks)
+    gl = torch.autograd.grad(out["loss"], [sd[k] for k in keys], allow_unused=True)
+    for k in keys:
+        sd[k].requires_grad_(False)
+    grads = dict(zip(keys, gl))
+    O.adam_step(sd, grads, opt, step_idx, hp.lr_eval if lr is None else lr, hp.weight_decay_eval)
+    out = {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in out.items()}
+    out["grads"] = grads
+    return out

@@ -80,6 +80,26 @@ extern "C" int stil_ema_update(float* ema, const float* model, long n, double mo
   return STIL_OK;
 }
 
+// CoTraining_SAINT.momentum_update_ema (models/SemiMultimodal/CoTraining_SAINT.py:102-105) applies
+// `v_ema.copy_(v_ema * m + (1 - m) * v_main)` to SAINT's int64 *_offset buffers as well: float32 arithmetic, then the copy
+// truncates toward zero -- so 29 becomes 28 at m = 0.996.  Same rounding sequence here; parity is with the reference as shipped.
+__global__ void ema_int_trunc_kernel(long long* __restrict__ e, const long long* __restrict__ v, int n, float m, float c) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float t0 = (float)e[i] * m, t1 = c * (float)v[i];
+  e[i] = (long long)(t0 + t1);
+}
+
+extern "C" int stil_ema_int_trunc(long long* ema, const long long* model, int n, double momentum, void* stream) {
+  STIL_REQUIRE(ema && model && n >= 0, "stil_ema_int_trunc: bad arguments");
+  if (n == 0) return STIL_OK;
+  hipLaunchKernelGGL(ema_int_trunc_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ema, model, n, (float)momentum,
+                     (float)(1.0 - momentum));
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
 // n must be a multiple of 1024 (tensor slots are 1024-aligned); chunk2tensor has n/1024 entries (-1 = padding only).
 // grad_scale multiplies every gradient first (1/world_size after a SUM all-reduce).
 extern "C" int stil_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,

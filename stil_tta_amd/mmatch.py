@@ -1,4 +1,4 @@
-"""MMatch baseline on the same HIP kernels: `models/SemiMultimodal/MMatch.py` (module) and
+"""MMatch / CoTraining (+ its SAINT variant) baselines on the same HIP kernels: `models/SemiMultimodal/MMatch.py` (module) and
 `models/SemiMultimodal/Multimodal_model.py` (concatenation backbone) of the reference, same class names, constructor,
 hooks, `state_dict` keys (187 for ResNet-18 / 5 columns, asserted against the reference when the golden vectors are generated).
 
@@ -50,6 +50,39 @@ class MultimodalBackbone(nn.Module):
         cls = self.encoder_tabular.run(x[1])[:, 0, :].contiguous()
         lin = lambda t, m: ops.linear(t, m.weight, m.bias)  # noqa: E731
         x_m = lin(torch.cat([lin(x_i, self.image_proj), cls], dim=1), self.multimodal_proj)
+        return lin(x_m, self.classifier_multimodal), lin(x_i, self.classifier_imaging), lin(cls, self.classifier_tabular), x_m
+
+
+class MultimodalBackboneSAINT(nn.Module):
+    """Multimodal_model_SAINT.py:37-195: the concatenation backbone with SAINT's row/column tabular encoder (embedding 32):
+    `tabular_proj` = Linear(32, C), `classifier_tabular` = Linear(32, K)."""
+
+    def __init__(self, hp, field_lengths):
+        super().__init__()
+        from .saint import SAINT, SAINT_DIM, register_saint_meta
+        self.encoder_imaging = ResNet(hp.model)
+        self.cat_cols = [i for i, c in enumerate(field_lengths) if int(c) != 1]
+        self.con_cols = [i for i, c in enumerate(field_lengths) if int(c) == 1]
+        cats = [int(field_lengths[i]) for i in self.cat_cols]
+        self.encoder_tabular = SAINT(cats, len(self.con_cols), hp.num_classes)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1))
+        C, Dt = hp.multimodal_embedding_dim, SAINT_DIM
+        self.image_proj = nn.Linear(hp.embedding_dim, C)
+        self.tabular_proj = nn.Linear(Dt, C) if Dt != C else nn.Identity()
+        self.multimodal_proj = nn.Linear(2 * C, hp.projection_dim)
+        self.classifier_multimodal = nn.Linear(hp.projection_dim, hp.num_classes)
+        self.classifier_imaging = nn.Linear(hp.embedding_dim, hp.num_classes)
+        self.classifier_tabular = nn.Linear(Dt, hp.num_classes)
+        register_saint_meta(self, cats)
+
+    def run(self, x, train: bool, masks=None):
+        """-> out_m, out_i, out_t, x_m  (Multimodal_model_SAINT.py:187-195); masks: the two feed-forward dropout keep-masks."""
+        from .saint import saint_forward_tabular
+        x_i = ops.tokmean(self.encoder_imaging.run(x[0], train))
+        cls = saint_forward_tabular(self, x[1], masks if train else None)[:, 0, :].contiguous()
+        lin = lambda t, m: ops.linear(t, m.weight, m.bias)  # noqa: E731
+        t_p = lin(cls, self.tabular_proj) if isinstance(self.tabular_proj, nn.Linear) else cls
+        x_m = lin(torch.cat([lin(x_i, self.image_proj), t_p], dim=1), self.multimodal_proj)
         return lin(x_m, self.classifier_multimodal), lin(x_i, self.classifier_imaging), lin(cls, self.classifier_tabular), x_m
 
 
@@ -236,10 +269,13 @@ class CoTraining(STiLModel):
         if fl is None:
             fl = torch.load(hp.field_lengths_tabular)
         self.field_lengths = [int(v) for v in fl]
-        self.model = MultimodalBackbone(hp, self.field_lengths)
+        # CoTrain_Pseudo_SAINT (CoTraining_SAINT.py, trainers/evaluate.py:163-165): the same module on the SAINT backbone
+        self.saint = hp.tabular_encoder == "saint" or getattr(hp, "algorithm_name", None) == "CoTrain_Pseudo_SAINT"
+        self._backbone = MultimodalBackboneSAINT if self.saint else MultimodalBackbone
+        self.model = self._backbone(hp, self.field_lengths)
         self.use_ema = bool(hp.use_ema)
         if self.use_ema:  # CoTraining.py:43-51
-            self.ema = MultimodalBackbone(hp, self.field_lengths)
+            self.ema = self._backbone(hp, self.field_lengths)
             self.ema.load_state_dict(self.model.state_dict())
             for q in self.ema.parameters():
                 q.requires_grad = False
@@ -259,12 +295,45 @@ class CoTraining(STiLModel):
             raise RuntimeError("stil_tta_amd: no HIP device visible; the training step has no CPU path")
         device = torch.device(device or "cuda")
         nn.Module.to(self, device)
-        teacher = self.ema if self.use_ema else MultimodalBackbone(self.hp, self.field_lengths).to(device)
+        teacher = self.ema if self.use_ema else self._backbone(self.hp, self.field_lengths).to(device)
         self.flat = FlatState(self.model, teacher, [], device)
+        self._rng_offset = 0
+        self._rng_step = torch.zeros(1, dtype=torch.int64, device=device)
+        self._int_pairs = []
+        if self.saint and self.use_ema:   # SAINT's persistent int64 *_offset buffers, teacher / student
+            keys = set(self.ema.state_dict().keys())
+            self._int_pairs = [(bt, bs) for (nt, bt), (_, bs) in zip(self.ema.named_buffers(), self.model.named_buffers())
+                               if bt.dtype == torch.int64 and "offset" in nt and nt in keys]
         return self
 
     def forward(self, x):
         return self.model.run(x, self.training)
+
+    def _saint_masks(self, B, masks):
+        """Keep-masks of SAINT's two feed-forward dropouts (p = 0.8, Multimodal_model_SAINT.py:112-115): injected (parity
+        tests, oracle layout) or drawn on the device."""
+        dev = self.prototypes.device
+        nf, h4 = len(self.field_lengths) + 1, 4 * 32
+        if masks is not None:
+            return {"ff_col": masks["ff_col"].to(device=dev, dtype=torch.uint8).contiguous(),
+                    "ff_row": masks["ff_row"].reshape(B, -1).to(device=dev, dtype=torch.uint8).contiguous()}
+        out = {"ff_col": ops.rng_mask((B, nf, h4), 0.8, self.hp.seed + 2, self._rng_offset, dev, self._rng_step),
+               "ff_row": ops.rng_mask((B, nf * h4), 0.8, self.hp.seed + 3, self._rng_offset, dev, self._rng_step)}
+        self._rng_offset += B * nf * h4
+        return out
+
+    def _ema_update(self):
+        """CoTraining.py:95-109.  SAINT + eman: the reference's EMA also runs over the int64 *_offset buffers of the SAINT
+        encoder (float32 arithmetic, truncating copy, CoTraining_SAINT.py:102-105); reproduced as shipped."""
+        hp = self.hp
+        if self.saint and bool(hp.eman):
+            old = [bt.clone() for bt, _ in self._int_pairs]
+            self.flat.ema_update(hp.ema_momentum, True)          # floats + counters (copies every int64 buffer)
+            for (bt, bs), o in zip(self._int_pairs, old):
+                bt.copy_(o)
+                lib().ema_int_trunc(_p(bt), _p(bs), bt.numel(), float(hp.ema_momentum), _stream())
+        else:
+            self.flat.ema_update(hp.ema_momentum, bool(hp.eman))
 
     def _confidence(self, probs, th):
         """(max_k p >= th) as a 0/1 float row mask."""
@@ -276,7 +345,7 @@ class CoTraining(STiLModel):
         lib().onehot_argmax(_p(probs), R, K, float(th), _p(onehot), _p(mask), _p(idx), _stream())
         return mask
 
-    def training_step(self, batch, _=None):
+    def training_step(self, batch, _=None, saint_masks=None):
         hp = self.hp
         self.setup_device()
         dev = self.prototypes.device
@@ -286,10 +355,13 @@ class CoTraining(STiLModel):
         self._check_identify(batch)                                                              # CoTraining.py:121-122
         x = (torch.cat((im_l, im_u)).to(dev, torch.float32).contiguous(), torch.cat((tab_l, tab_u)).to(dev, torch.float32).contiguous())
         y_l = y_l.to(dev)
-        y_m, y_i, y_t, _x = self.model.run(x, True)
+        if self.saint:
+            y_m, y_i, y_t, _x = self.model.run(x, True, self._saint_masks(x[0].shape[0], saint_masks))
+        else:
+            y_m, y_i, y_t, _x = self.model.run(x, True)
         with torch.no_grad():
             if self.use_ema:  # CoTraining.py:128-133
-                self.flat.ema_update(hp.ema_momentum, bool(hp.eman))
+                self._ema_update()
                 _, yi_e, yt_e, _ = self.ema.run(x, False)
             else:
                 yi_e, yt_e = y_i.detach(), y_t.detach()

@@ -117,6 +117,59 @@ def _ff(ffm: _FeedForward, xn, mask, p):
     return ops.linear(h, ffm.net[3].weight, ffm.net[3].bias)
 
 
+def register_saint_meta(self, cats):
+    """Column metadata of the fused embedding kernel as non-persistent buffers (absent from the state_dict)."""
+    rowcol = torch.cat([torch.zeros(1, dtype=torch.int32)] + [torch.full((c,), j + 1, dtype=torch.int32) for j, c in enumerate(cats)])
+    self.register_buffer("_cat_cols", torch.tensor(self.cat_cols, dtype=torch.int32), persistent=False)
+    self.register_buffer("_con_cols", torch.tensor(self.con_cols, dtype=torch.int32), persistent=False)
+    self.register_buffer("_rowcol", rowcol, persistent=False)
+    self.ff_drop = 0.8
+    self._ncat = len(cats)
+
+
+def saint_forward_tabular(self, x_t, masks=None):
+    """forward_tabular of STiLModel_SAINT_backbone.py:159-184 / Multimodal_model_SAINT.py:160-185 for a module that holds
+    `encoder_tabular` (SAINT), `cls_token` and the column metadata of register_saint_meta.  The categorical offsets are read
+    from the module's LIVE `categories_offset` buffer (a loaded checkpoint, or the teacher copy that CoTraining_SAINT's EMA
+    alters, may differ from the constructor's values)."""
+    enc = self.encoder_tabular
+    meta = dict(ncat=self._ncat, ncon=len(self.con_cols), hid=100, cat_cols=self._cat_cols, con_cols=self._con_cols,
+                offs=enc.categories_offset.to(torch.int32), rowcol=self._rowcol)
+    mlp_params = []
+    for m in enc.simple_MLP:
+        mlp_params += [m.layers[0].weight, m.layers[0].bias, m.layers[2].weight, m.layers[2].bias]
+    x = ops.SaintEmbedColMlpFn.apply(x_t.contiguous(), enc.embeds.weight, enc.pos_encodings.weight, meta, *mlp_params)
+    B, n, d = x.shape
+    a1, f1, a2, f2 = enc.transformer.layers[0]
+    mk = (lambda k: None) if masks is None else (lambda k: masks[k])
+
+    def col_attn(xn):
+        at = a1.fn.fn
+        qkv = ops.linear(xn, at.to_qkv.weight, None)
+        o = ops.attention(qkv, at.heads, [(0, n, 0, n)])
+        return ops.linear(o, at.to_out.weight, at.to_out.bias)
+
+    def row_attn(xn):  # inter-sample attention: sequence = the batch, 4 heads x 64 (SAINT/model_util.py:79-87,117-119)
+        at = a2.fn.fn
+        qkv = ops.linear(xn, at.to_qkv.weight, None)  # [B, 3*256]
+        inner = at.heads * at.dim_head
+        outs = []
+        for h in range(at.heads):
+            q = qkv[:, h * 64:(h + 1) * 64].contiguous()
+            k = qkv[:, inner + h * 64: inner + (h + 1) * 64].contiguous()
+            v = qkv[:, 2 * inner + h * 64: 2 * inner + (h + 1) * 64].contiguous()
+            P = ops.RowSoftmaxFn.apply(ops.MatmulNTFn.apply(q, k, at.dim_head ** -0.5))
+            outs.append(ops.MatmulNNFn.apply(P, v))
+        return ops.linear(torch.cat(outs, dim=1), at.to_out.weight, at.to_out.bias)
+
+    x = _prenorm_res(x, a1, col_attn)
+    x = _prenorm_res(x, f1, lambda xn: _ff(f1.fn.fn, xn, mk("ff_col"), self.ff_drop))
+    xr = x.reshape(B, n * d)
+    xr = _prenorm_res(xr, a2, row_attn)
+    xr = _prenorm_res(xr, f2, lambda xn: _ff(f2.fn.fn, xn, mk("ff_row"), self.ff_drop))
+    return xr.reshape(B, n, d)
+
+
 class SaintBackbone(nn.Module):
     """DisCoAttentionBackbone of STiLModel_SAINT_backbone.py:37-234 (same heads as the base backbone)."""
 
@@ -138,53 +191,10 @@ class SaintBackbone(nn.Module):
         self.classifier_multimodal = nn.Linear(C * 3, hp.num_classes)
         self.classifier_imaging = nn.Linear(C * 2, hp.num_classes)
         self.classifier_tabular = nn.Linear(C * 2, hp.num_classes)
-        ncat = len(cats)
-        offs = self.encoder_tabular.categories_offset.to(torch.int32)
-        rowcol = torch.cat([torch.zeros(1, dtype=torch.int32)] + [torch.full((c,), j + 1, dtype=torch.int32) for j, c in enumerate(cats)])
-        self.register_buffer("_cat_cols", torch.tensor(self.cat_cols, dtype=torch.int32), persistent=False)
-        self.register_buffer("_con_cols", torch.tensor(self.con_cols, dtype=torch.int32), persistent=False)
-        self.register_buffer("_offs", offs, persistent=False)
-        self.register_buffer("_rowcol", rowcol, persistent=False)
-        self.ff_drop = 0.8
-        self._ncat = ncat
+        register_saint_meta(self, cats)
 
     def forward_tabular(self, x_t, masks=None):
-        enc = self.encoder_tabular
-        meta = dict(ncat=self._ncat, ncon=len(self.con_cols), hid=100, cat_cols=self._cat_cols, con_cols=self._con_cols,
-                    offs=self._offs, rowcol=self._rowcol)
-        mlp_params = []
-        for m in enc.simple_MLP:
-            mlp_params += [m.layers[0].weight, m.layers[0].bias, m.layers[2].weight, m.layers[2].bias]
-        x = ops.SaintEmbedColMlpFn.apply(x_t.contiguous(), enc.embeds.weight, enc.pos_encodings.weight, meta, *mlp_params)
-        B, n, d = x.shape
-        a1, f1, a2, f2 = enc.transformer.layers[0]
-        mk = (lambda k: None) if masks is None else (lambda k: masks[k])
-
-        def col_attn(xn):
-            at = a1.fn.fn
-            qkv = ops.linear(xn, at.to_qkv.weight, None)
-            o = ops.attention(qkv, at.heads, [(0, n, 0, n)])
-            return ops.linear(o, at.to_out.weight, at.to_out.bias)
-
-        def row_attn(xn):  # inter-sample attention: sequence = the batch, 4 heads x 64 (SAINT/model_util.py:79-87,117-119)
-            at = a2.fn.fn
-            qkv = ops.linear(xn, at.to_qkv.weight, None)  # [B, 3*256]
-            inner = at.heads * at.dim_head
-            outs = []
-            for h in range(at.heads):
-                q = qkv[:, h * 64:(h + 1) * 64].contiguous()
-                k = qkv[:, inner + h * 64: inner + (h + 1) * 64].contiguous()
-                v = qkv[:, 2 * inner + h * 64: 2 * inner + (h + 1) * 64].contiguous()
-                P = ops.RowSoftmaxFn.apply(ops.MatmulNTFn.apply(q, k, at.dim_head ** -0.5))
-                outs.append(ops.MatmulNNFn.apply(P, v))
-            return ops.linear(torch.cat(outs, dim=1), at.to_out.weight, at.to_out.bias)
-
-        x = _prenorm_res(x, a1, col_attn)
-        x = _prenorm_res(x, f1, lambda xn: _ff(f1.fn.fn, xn, mk("ff_col"), self.ff_drop))
-        xr = x.reshape(B, n * d)
-        xr = _prenorm_res(xr, a2, row_attn)
-        xr = _prenorm_res(xr, f2, lambda xn: _ff(f2.fn.fn, xn, mk("ff_row"), self.ff_drop))
-        return xr.reshape(B, n, d)
+        return saint_forward_tabular(self, x_t, masks)
 
     def forward_all(self, x, train: Optional[bool] = None, mi_masks=None, cache=None, x_i=None):
         train = self.training if train is None else train

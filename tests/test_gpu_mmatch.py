@@ -132,3 +132,51 @@ def test_cotraining_step_matches_reference_golden(name):
             if abs(float(v.sum()) - float(fx[key])) > 5e-5 * (1.0 + float(fx["sabs_" + key[5:]])):
                 bad.append(("state " + key[5:], float(v.sum()), float(fx[key])))
     assert not bad, f"{len(bad)} mismatches, first: {bad[:8]}"
+
+
+@pytest.mark.parametrize("name", list(GM.COS_CASES))
+def test_cotraining_saint_step_matches_reference_golden(name):
+    """CoTrain_Pseudo_SAINT (models/SemiMultimodal/CoTraining_SAINT.py): SAINT tabular encoder with injected feed-forward
+    dropout masks; under eman the teacher's int64 offset buffers must end up as the reference's EMA leaves them (29 -> 28)."""
+    from stil_tta_amd import CoTraining
+    from stil_tta_amd.flat import StilAdam
+    fx = np.load(os.path.join(GOLD, name + ".npz"))
+    hp, sd, batch, epoch, masks = GM.build_cos_case(name)
+    hp.co_threshold = float(fx["meta_co_threshold"])
+    m = CoTraining(dict(vars(hp)))
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict({k: v.clone() for k, v in sd.items()})
+    m.setup_device("cuda"); m.train(); m.current_epoch = epoch
+    opt = StilAdam(m.flat, lr=hp.lr_eval)
+    opt.zero_grad()
+    loss = m.training_step(_to_dev(batch), 0, saint_masks=masks)
+    loss.backward()
+    opt.step()
+    torch.cuda.synchronize()
+    bad = []
+    for k in GM.CO_SCALARS + ["y_hat_m", "y_hat_i", "y_hat_t", "y_hat_i_e", "y_hat_t_e", "pseudo_label_i", "pseudo_label_t"]:
+        ok, err = _close(m.last[k].detach().cpu().numpy(), fx["out_" + k])
+        if not ok:
+            bad.append((k, err))
+    assert np.array_equal(m.last["mask_i"].cpu().numpy() > 0.5, fx["out_mask_i"]) and np.array_equal(m.last["mask_t"].cpu().numpy() > 0.5, fx["out_mask_t"])
+    params = dict(m.named_parameters())
+    for key in fx.files:
+        if not key.startswith("gnorm_"):
+            continue
+        pname = key[6:]
+        p = params[pname]
+        if "g64norm_" + pname not in fx.files:
+            assert not p._stil_touched, pname
+            continue
+        n64, e32 = float(fx["g64norm_" + pname]), float(fx["gerr32_" + pname])
+        if abs(float(p._gslot.double().norm()) - n64) > (3 * e32 + 1e-2) * n64 + 1e-7:
+            bad.append(("gnorm " + pname, float(p._gslot.double().norm()), n64))
+    msd = m.state_dict()
+    for key in fx.files:
+        if key.startswith("ssum_"):
+            v = msd[key[5:]].double()
+            if abs(float(v.sum()) - float(fx[key])) > 5e-5 * (1.0 + float(fx["sabs_" + key[5:]])):
+                bad.append(("state " + key[5:], float(v.sum()), float(fx[key])))
+        elif key.startswith("state_"):
+            assert np.array_equal(msd[key[6:]].cpu().numpy(), fx[key]), (key, msd[key[6:]].tolist(), fx[key].tolist())
+    assert not bad, f"{len(bad)} mismatches, first: {bad[:8]}"

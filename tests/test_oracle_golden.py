@@ -153,6 +153,36 @@ def test_cotraining_oracle_matches_reference_golden(name):
             assert abs(float(sd[key[5:]].double().sum()) - float(fx[key])) <= 2e-5 * (1.0 + float(fx["sabs_" + key[5:]])), key
 
 
+@pytest.mark.parametrize("name", list(GM.COS_CASES))
+def test_cotraining_saint_oracle_matches_reference_golden(name):
+    """CoTraining_SAINT.py: incl. the teacher's int64 offset buffers as the reference's EMA leaves them (29 -> 28 under eman)."""
+    fx = np.load(os.path.join(GOLD, name + ".npz"))
+    hp, sd, batch, epoch, masks = GM.build_cos_case(name)
+    hp.co_threshold = float(fx["meta_co_threshold"])
+    out = MO.cotrain_saint_full_step(sd, {}, 1, batch, hp, epoch, masks)
+    for k in GM.CO_SCALARS:
+        assert _close(out[k].numpy(), fx["out_" + k], 2e-5), k
+    for k in GM.CO_TENSORS:
+        a, b = out[k].numpy(), fx["out_" + k]
+        assert (np.array_equal(a, b) if b.dtype == np.bool_ else _close(a, b, 2e-5)), k
+    for key in fx.files:
+        if key.startswith("ssum_"):
+            assert abs(float(sd[key[5:]].double().sum()) - float(fx[key])) <= 2e-5 * (1.0 + float(fx["sabs_" + key[5:]])), key
+        elif key.startswith("state_"):
+            assert np.array_equal(sd[key[6:]].numpy(), fx[key]), key
+    if hp.eman:
+        assert sd["ema.encoder_tabular.categories_offset"].tolist() == [0, 1, 4, 28] and sd["model.encoder_tabular.categories_offset"].tolist() == [0, 1, 4, 29]
+
+
+def test_cotraining_saint_state_dict_layout():
+    from stil_tta_amd import CoTraining
+    hp = MO.cotrain_saint_hparams(model="resnet18", embedding_dim=512, field_lengths=GM.FLS, num_classes=5, batch_size=16)
+    sd = MO.cotrain_saint_init_state(hp, seed=0)
+    got = CoTraining(dict(vars(hp))).state_dict()
+    assert list(got.keys()) == list(sd.keys())
+    assert all(tuple(got[k].shape) == tuple(sd[k].shape) and got[k].dtype == sd[k].dtype for k in sd)
+
+
 def test_tab_corrupt_restatement_matches_reference_golden():
     """datasets/ContrastiveImagingAndTabularDataset.py:146-158: the restated `corrupt` (draws made explicit) against the
     outputs of the reference's own method under the same draws (tests/golden/tab_corrupt.npz, oracle/make_golden_data.py)."""
