@@ -217,3 +217,43 @@ def test_match_baselines_two_ranks_share_queues_and_banks():
     assert float(si["model.bank"][:, [3, 4, 20, 21]].norm(dim=0).sub(1).abs().max()) < 1e-5
     assert not torch.equal(si["model.bank"][:, 3], si["model.bank"][:, 4])
     assert int(si["model.DA_ptr"]) == 1
+
+
+def test_freematch_kernels_against_torch():
+    """stil_freematch_update / stil_freematch_entropy against the reference formulas (freematch_model.py:132-168,
+    freematch_utils.py:18-47) in float64: more rows than one workgroup has threads, K = 286, an empty mask, a full mask."""
+    from stil_tta_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for R, K in ((14, 5), (300, 286), (33, 2)):
+        probs = torch.softmax(torch.randn(R, K, generator=g) * 3, dim=1)
+        p_model = torch.softmax(torch.randn(K, generator=g), dim=0)
+        label_hist = torch.softmax(torch.randn(K, generator=g), dim=0)
+        time_p = torch.rand(1, generator=g) * 0.5 + 0.3
+        pm_d, lh_d, tp_d = p_model.cuda(), label_hist.cuda(), time_p.cuda()
+        mask, onehot, idx = ops.freematch_update(probs.cuda(), pm_d, lh_d, tp_d, 0.999)
+        P = probs.double()
+        mp_, mi_ = P.max(dim=-1)
+        tp = time_p.double() * 0.999 + 0.001 * mp_.mean()
+        pm = p_model.double() * 0.999 + 0.001 * P.mean(0)
+        hist = torch.bincount(mi_, minlength=K).double()
+        lh = label_hist.double() * 0.999 + 0.001 * hist / hist.sum()
+        ref_mask = mp_ >= tp * (pm / pm.max())[mi_]
+        assert torch.equal(idx.cpu().long(), mi_) and torch.equal(onehot.cpu().argmax(1), mi_) and float(onehot.sum()) == R
+        assert float((pm_d.cpu().double() - pm).abs().max()) < 1e-7 and float((lh_d.cpu().double() - lh).abs().max()) < 1e-7
+        assert abs(float(tp_d) - float(tp)) < 1e-7
+        margin = (mp_ - tp * (pm / pm.max())[mi_]).abs() > 1e-6            # rows not within rounding of the threshold
+        assert torch.equal((mask.cpu() > 0.5)[margin], ref_mask[margin])
+        z = torch.randn(R, K, generator=g) * 2
+        for which in ("mixed", "empty", "full"):
+            m = {"mixed": (torch.rand(R, generator=g) < 0.5).float(), "empty": torch.zeros(R), "full": torch.ones(R)}[which]
+            zd = z.cuda().requires_grad_(True)
+            loss = ops.FreeMatchEntropyFn.apply(zd, m.cuda(), pm_d, lh_d)
+            loss.backward()
+            if float(m.sum()) == 0:
+                assert float(loss) == 0.0 and float(zd.grad.abs().max()) == 0.0
+                continue
+            z64 = z.double().requires_grad_(True)
+            ref = XO.freematch_entropy_loss(m, z64, pm_d.cpu().double(), lh_d.cpu().double())
+            ref.backward()
+            assert abs(float(loss) - float(ref)) <= 2e-5 * (1 + abs(float(ref))), (R, K, which, float(loss), float(ref))
+            assert float((zd.grad.cpu().double() - z64.grad).abs().max()) <= 2e-5 * (1e-3 + float(z64.grad.abs().max())), (R, K, which)
