@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--ncat", type=int, default=16)
     ap.add_argument("--ncon", type=int, default=48)
     ap.add_argument("--classes", type=int, default=286)
-    ap.add_argument("--variant", choices=["dvm", "saint", "cardiac", "mmatch"], default="dvm",
+    ap.add_argument("--variant", choices=["dvm", "saint", "cardiac", "mmatch", "comatch", "simmatch", "freematch"], default="dvm",
                     help="dvm = BASELINE configs[1..2] (the bench line); saint = config 4; cardiac = config 5 (26 cat + 49 con, K=2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32, help="batch of the CPU baseline (BASELINE.md section 3: 32; 256 = the bench's own batch, ~2 min per step)")
@@ -104,16 +104,26 @@ def main():
     if a.variant == "mmatch":  # the MMatch baseline of the reference on the same kernels (configs/config_dvm_MMatch.yaml)
         from stil_tta_amd import MMatch as STiLModel  # noqa: F811
         extra = dict(DA=True, alpha=1.0, mmatch_lambda=5.0)
+    match = a.variant in ("comatch", "simmatch", "freematch")  # the Match baselines (configs/config_dvm_Multi*Match.yaml) on the same kernels
+    if match:
+        import stil_tta_amd
+        STiLModel = {"comatch": stil_tta_amd.CoMatch, "simmatch": stil_tta_amd.SimMatch, "freematch": stil_tta_amd.FreeMatch}[a.variant]  # noqa: F811
+        extra = dict(K=2560, DA=True)
     m = STiLModel(dict(field_lengths=fl, num_classes=a.classes, img_size=a.img, batch_size=a.batch, start_epoch=35,
                        repeat_ratio=1.0, seed=2022 + rank, **extra))
     m.setup_device(dev)
     m.train()
     m.current_epoch = 36  # > start_epoch: every loss term of STiLModel.py:345 is live
     g = torch.Generator().manual_seed(7)
-    if a.variant != "mmatch":
+    if a.variant != "mmatch" and not match:
         m.prototypes.copy_(torch.nn.functional.normalize(torch.randn(a.classes, 128, generator=g)).to(dev))
     opt = StilAdam(m.flat, lr=1e-4)
     batch = synthetic_batch(fl, a.classes, a.batch, a.img, seed=2022 + rank, device=dev)
+    if match:  # (x, y, index) / ((weak, strong[, strong2]), y) of trainers/evaluate.py:50-83, from the same synthetic tensors
+        (_, iml), (_, tabl), yl = batch["l"][0], batch["l"][1], batch["l"][2]
+        (_, imu), (_, tabu), yu = batch["u"][0], batch["u"][1], batch["u"][2]
+        views = [(imu, tabu), (imu.flip(3).contiguous(), tabu)] + ([(imu.flip(2).contiguous(), tabu)] if a.variant == "comatch" else [])
+        batch = {"l": ((iml, tabl), yl, torch.arange(len(yl), device=dev)), "u": (views, yu)}
 
     if a.graph:
         from stil_tta_amd.driver import GraphedTrainStep
@@ -211,7 +221,7 @@ def main():
         out = dict(metric="training samples/sec (labeled+unlabeled) for DVM STiL", value=round(value, 2), unit="samples/s",
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload=f"config_{'cardiac' if a.variant == 'cardiac' else 'dvm'}_{'MMatch' if a.variant == 'mmatch' else 'STiL'}{'_SAINT' if a.variant == 'saint' else ''} ResNet-50 + {'SAINT' if a.variant == 'saint' else 'Transformer'} tabular, batch {a.batch}/GPU "
+                   config=dict(workload=f"config_{'cardiac' if a.variant == 'cardiac' else 'dvm'}_{dict(mmatch='MMatch', comatch='MultiCoMatch', simmatch='MultiSimMatch', freematch='MultiFreeMatch').get(a.variant, 'STiL')}{'_SAINT' if a.variant == 'saint' else ''} ResNet-50 + {'SAINT' if a.variant == 'saint' else 'Transformer'} tabular, batch {a.batch}/GPU "
                                         f"({a.batch // 8} labelled + {a.batch - a.batch // 8} unlabelled), {a.img}x{a.img} + "
                                         f"{a.ncat + a.ncon} columns, K={a.classes}, epoch > start_epoch, MI dropout on",
                                global_batch=a.batch * world, parallelism=f"dp{world}", precision="fp32-exact MFMA",
