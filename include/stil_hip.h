@@ -288,6 +288,13 @@ int stil_aug_gray_mean(const unsigned char* src_u8, const float* src_f32, const 
  *   (tmp: same size, the row-pass intermediate). */
 int stil_aug_blur(const unsigned char* src_u8, const float* src_f32, const float* sigma, float* tmp, float* out, int B, int H,
                   int W, int ksize, float scale, void* stream);
+/* stil_aug_rotate: the whole source image rotated by angle[b] degrees (counter-clockwise) about its centre, same size, bilinear,
+ *   borders mirrored without repeating the edge pixel (A.Rotate / cv2.BORDER_REFLECT_101; utils/utils.py:82,112,170) -> float CHW.
+ * stil_aug_hue: torchvision's float adjust_hue in place on float CHW images in [0,1] (hue[b] in [-0.5, 0.5], may be null), then
+ *   the 3-channel grey image where gray[b] != 0 (may be null): the tail of the strong-view colour jitter, utils/utils.py:225-226. */
+int stil_aug_rotate(const unsigned char* src_u8, const float* src_f32, const float* angle, float* out, int B, int H, int W,
+                    float scale, void* stream);
+int stil_aug_hue(float* img, const float* hue, const float* gray, int B, int H, int W, void* stream);
 int stil_aug_resize(const unsigned char* src_u8, const float* src_f32, const int* box, const unsigned char* flip,
                     const float* jitter, const float* gmean, float* out, int B, int H, int W, int P, float scale,
                     void* stream);

@@ -11,7 +11,9 @@ Random draws are made here (numpy Generator on the host for the few scalars per 
 stil_tab_corrupt_draw for the table) or injected (`draws=`) by the parity tests.  What is pinned to the reference:
 `corrupt` (golden vectors recorded from the reference's own method).  The image transforms follow torchvision's float
 tensor formulas (the reference's non-`augmentation_speedup` branch); albumentations / cv2 / torchvision are absent
-offline, so they are tested against PyTorch restatements only (unpinned); the cardiac pipeline's Rotate is not built.
+offline, so they are tested against PyTorch restatements only (unpinned).  `kind` selects the reference's transform
+family: "contrastive" (grab_image_augmentations), "hard_eval" / "soft_eval" (utils/utils.py:94-186, the labelled set of the
+Match baselines), "weak" / "strong" (:187-256, their unlabelled views); rotation follows A.Rotate (bilinear, reflect-101).
 """
 from __future__ import annotations
 
@@ -123,40 +125,111 @@ def gaussian_blur(src: torch.Tensor, sigma, ksize: int = 29) -> torch.Tensor:
     return out
 
 
+def rotate(src: torch.Tensor, angle) -> torch.Tensor:
+    """A.Rotate / RandomRotation per sample: angle [B] degrees, counter-clockwise, about the centre, same size -> float [B,3,H,W]."""
+    _chk(src)
+    u8 = src.dtype == torch.uint8
+    B = src.shape[0]
+    H, W = (src.shape[1], src.shape[2]) if u8 else (src.shape[2], src.shape[3])
+    angle = torch.as_tensor(angle, dtype=torch.float32).to(src.device).contiguous()
+    out = torch.empty((B, 3, H, W), dtype=torch.float32, device=src.device)
+    lib().aug_rotate(_p(src) if u8 else None, None if u8 else _p(src), _p(angle), _p(out), B, H, W, 1.0 / 255.0 if u8 else 1.0, _stream())
+    return out
+
+
+def adjust_hue_(img: torch.Tensor, hue=None, gray=None) -> torch.Tensor:
+    """In place on float [B,3,H,W] in [0,1]: torchvision adjust_hue(hue[b]) then the grey image where gray[b] != 0."""
+    _chk(img)
+    B, _, H, W = img.shape
+    hue = None if hue is None else torch.as_tensor(hue, dtype=torch.float32).to(img.device).contiguous()
+    gray = None if gray is None else torch.as_tensor(gray, dtype=torch.float32).to(img.device).contiguous()
+    lib().aug_hue(_p(img), _p(hue), _p(gray), B, H, W, _stream())
+    return img
+
+
+# transform families of utils/utils.py (torchvision branch): RandomResizedCrop scale, rotation limit, ColorJitter (amount,
+# probability, hue), grayscale probability, GaussianBlur (kernel, probability, "pre" = on the source image before the crop /
+# "post" = on the cropped view).  dvm only: gray, blur.
+def _policy(kind: str, dvm: bool, crop_scale_lower: float = 0.08):
+    if kind == "contrastive":   # grab_image_augmentations, :46-91
+        return dict(scale=(crop_scale_lower, 1.0), jitter=(0.8, 0.8, 0.0), gray=0.2, blur=(29, 0.5, "pre")) if dvm else \
+            dict(scale=(0.2, 1.0), rotate=45.0, jitter=(0.5, 1.0, 0.0))
+    if kind == "hard_eval":     # grab_hard_eval_image_augmentations, :139-186
+        return dict(scale=(0.6, 1.0), jitter=(0.8, 0.8, 0.0), gray=0.2, blur=(29, 0.5, "pre")) if dvm else \
+            dict(scale=(0.6, 1.0), rotate=45.0, jitter=(0.5, 1.0, 0.0))
+    if kind == "soft_eval":     # grab_soft_eval_image_augmentations, :94-136
+        return dict(scale=(0.8, 1.0), rotate=20.0, jitter=(0.25, 1.0, 0.0))
+    if kind == "weak":          # grab_weak_image_augmentations, :187-216
+        return dict(scale=(0.2, 1.0))
+    if kind == "strong":        # grab_strong_image_augmentations, :219-256
+        d = dict(scale=(0.2, 1.0), jitter=(0.4, 0.8, 0.1), blur=(19, 0.5, "post"))
+        if dvm:
+            d["gray"] = 0.2
+        return d
+    raise ValueError(f"unknown transform family {kind}")
+
+
 class ImageAugmenter:
-    """grab_image_augmentations (utils/utils.py:46-91) + default_transform (ContrastiveImagingAndTabularDataset.py:66-90):
-    dvm: ColorJitter(0.8, 0.8, 0.8) p=0.8, ToGray p=0.2, RandomResizedCrop(scale=(0.08, 1), ratio=(3/4, 4/3)), HFlip p=0.5;
-    + GaussianBlur(29, sigma U(0.1, 2)) p=0.5 on the source image; cardiac: HFlip p=0.5, ColorJitter(0.5, 0.5, 0.5),
-    RandomResizedCrop(scale=(0.2, 1))  (its Rotate(45) is not built).
+    """One of the reference's transform families (utils/utils.py:46-256, see _policy) + default_transform
+    (ContrastiveImagingAndTabularDataset.py:66-90) as batch launches.  contrastive/dvm: ColorJitter(0.8, 0.8, 0.8) p=0.8,
+    ToGray p=0.2, GaussianBlur(29, sigma U(0.1, 2)) p=0.5 on the source image, RandomResizedCrop(scale=(0.08, 1), ratio=(3/4,
+    4/3)), HFlip p=0.5; contrastive/cardiac: HFlip, Rotate(45), ColorJitter(0.5, 0.5, 0.5), RandomResizedCrop(scale=(0.2, 1)).
     Every image is augmented with probability `augmentation_rate`, otherwise only resized (generate_imaging_views)."""
 
-    def __init__(self, img_size: int, target: str = "dvm", augmentation_rate: float = 1.0, seed: int = 2022):
+    def __init__(self, img_size: int, target: str = "dvm", augmentation_rate: float = 1.0, seed: int = 2022, kind: str = "contrastive",
+                 crop_scale_lower: float = 0.08):
         self.P, self.dvm, self.rate = int(img_size), target.lower() == "dvm", float(augmentation_rate)
+        self.policy = _policy(kind, self.dvm, crop_scale_lower)
         self.rng = np.random.default_rng(seed)
 
     def draw(self, B: int, H: int, W: int) -> Dict[str, np.ndarray]:
-        r = self.rng
+        r, pol = self.rng, self.policy
         aug = r.random(B) < self.rate
-        boxes = rrc_boxes(H, W, B, scale=(0.08, 1.0) if self.dvm else (0.2, 1.0), rng=r)
+        boxes = rrc_boxes(H, W, B, scale=pol["scale"], rng=r)
         boxes[~aug] = np.array([0, 0, H, W], dtype=np.int32)
-        flip = ((r.random(B) < 0.5) & aug).astype(np.uint8)
-        amt = 0.8 if self.dvm else 0.5
-        jit = np.ones((B, 4), dtype=np.float32)
-        on = aug & ((r.random(B) < 0.8) if self.dvm else np.ones(B, dtype=bool))
-        jit[:, :3] = np.where(on[:, None], r.uniform(max(0.0, 1.0 - amt), 1.0 + amt, size=(B, 3)), 1.0)
-        jit[:, 3] = ((r.random(B) < 0.2) & aug).astype(np.float32) if self.dvm else 0.0
-        sigma = np.where(aug & (r.random(B) < 0.5), r.uniform(0.1, 2.0, size=B), 0.0).astype(np.float32) if self.dvm else np.zeros(B, np.float32)
-        return dict(boxes=boxes, flip=flip, jitter=jit, sigma=sigma)
+        d = dict(boxes=boxes, flip=((r.random(B) < 0.5) & aug).astype(np.uint8), aug=aug)
+        if "jitter" in pol:
+            amt, prob, hue = pol["jitter"]
+            jit = np.ones((B, 4), dtype=np.float32)
+            on = aug & (r.random(B) < prob)
+            jit[:, :3] = np.where(on[:, None], r.uniform(max(0.0, 1.0 - amt), 1.0 + amt, size=(B, 3)), 1.0)
+            jit[:, 3] = 0.0
+            gray = ((r.random(B) < pol["gray"]) & aug).astype(np.float32) if "gray" in pol else np.zeros(B, np.float32)
+            if hue > 0.0:   # hue comes before the grey conversion: both go to the hue kernel
+                d["hue"] = np.where(on, r.uniform(-hue, hue, size=B), 0.0).astype(np.float32)
+                d["gray_after_hue"] = gray
+            else:
+                jit[:, 3] = gray
+            d["jitter"] = jit
+        if "blur" in pol:
+            k, prob, when = pol["blur"]
+            d["sigma"] = np.where(aug & (r.random(B) < prob), r.uniform(0.1, 2.0, size=B), 0.0).astype(np.float32)
+        if "rotate" in pol:
+            d["angle"] = np.where(aug, r.uniform(-pol["rotate"], pol["rotate"], size=B), 0.0).astype(np.float32)
+        return d
 
-    def __call__(self, src: torch.Tensor, draws: Optional[Dict[str, np.ndarray]] = None):
-        """-> (augmented view, unaugmented resized image), both float [B,3,P,P]."""
+    def __call__(self, src: torch.Tensor, draws: Optional[Dict[str, np.ndarray]] = None, want_orig: bool = True):
+        """-> (augmented view, unaugmented resized image or None), float [B,3,P,P]."""
         u8 = src.dtype == torch.uint8
         B = src.shape[0]
         H, W = (src.shape[1], src.shape[2]) if u8 else (src.shape[2], src.shape[3])
         d = draws or self.draw(B, H, W)
+        pol = self.policy
         sg = d.get("sigma")
-        blurred = gaussian_blur(src, sg) if (sg is not None and float(np.max(sg)) > 0.0 and min(H, W) > 14) else src
-        view = resize_crop(blurred, d["boxes"], self.P, d.get("flip"), d.get("jitter"))
+        blur_k, _, blur_when = pol.get("blur", (29, 0.0, "pre"))
+        on = sg is not None and float(np.max(sg)) > 0.0
+        x = src
+        if d.get("angle") is not None and float(np.abs(d["angle"]).max()) > 0.0:
+            x = rotate(x, d["angle"])
+        if on and blur_when == "pre" and min(H, W) > blur_k // 2:
+            x = gaussian_blur(x, sg, blur_k)
+        view = resize_crop(x, d["boxes"], self.P, d.get("flip"), d.get("jitter"))
+        if d.get("hue") is not None:
+            adjust_hue_(view, d["hue"], d.get("gray_after_hue"))
+        if on and blur_when == "post" and self.P > blur_k // 2:
+            view = gaussian_blur(view, sg, blur_k)
+        if not want_orig:
+            return view, None
         full = np.tile(np.array([[0, 0, H, W]], dtype=np.int32), (B, 1))
         return view, resize_crop(src, full, self.P)
 
@@ -189,3 +262,65 @@ class ContrastiveBatchBuilder:
         dev = self.table.device
         return ([torch.zeros(b, device=dev), view], [clean, corrupted], self.labels.index_select(0, index), orig,
                 torch.full((b,), self.labelled, dtype=torch.bool, device=dev))
+
+
+class EvalTrainBatchBuilder:
+    """ImagingAndTabularDataset(train=True, return_index=True).__getitem__ + default_collate (datasets/ImagingAndTabularDataset.py:
+    158-190): the LABELLED part of the Match baselines' batches -> ((image [b,3,P,P], table [b,n]), y [b], index [b]).  With
+    probability eval_train_augment_rate a sample gets the hard-eval transform and a corrupted table, otherwise it is only
+    resized and keeps its clean table."""
+
+    def __init__(self, images, table, labels, img_size: int, target: str = "dvm", corruption_rate: float = 0.3,
+                 eval_train_augment_rate: float = 0.8, device="cuda", seed: int = 2022):
+        self.images = images.to(device)
+        self.table = torch.as_tensor(table, dtype=torch.float32).to(device)
+        self.labels = torch.as_tensor(labels, dtype=torch.int64).to(device)
+        self.corrupt = TabularCorruptor(self.table, corruption_rate, device, seed) if corruption_rate and corruption_rate > 0 else None
+        self.augment = ImageAugmenter(img_size, target, eval_train_augment_rate, seed + 1, kind="hard_eval")
+
+    def __len__(self):
+        return len(self.labels)
+
+    def __call__(self, index: torch.Tensor, draws=None):
+        index = torch.as_tensor(index).to(self.table.device, torch.int64)
+        clean = self.table.index_select(0, index)
+        src = self.images.index_select(0, index)
+        u8 = src.dtype == torch.uint8
+        H, W = (src.shape[1], src.shape[2]) if u8 else (src.shape[2], src.shape[3])
+        d = (draws or {}).get("image") or self.augment.draw(len(index), H, W)
+        view, _ = self.augment(src, d, want_orig=False)
+        tab = clean
+        if self.corrupt is not None:
+            aug = torch.as_tensor(d["aug"]).to(clean.device)
+            tab = torch.where(aug[:, None], self.corrupt(clean, (draws or {}).get("table")), clean)
+        return (view, tab), self.labels.index_select(0, index), index
+
+
+class StrongWeakBatchBuilder:
+    """StrongWeakImagingAndTabularDataset.__getitem__ + default_collate (datasets/StrongWeakImagingAndTabularDataset.py:166-196):
+    the UNLABELLED part of the Match baselines' batches -> ([(weak image, weakly corrupted table), (strong image, strongly
+    corrupted table)[, a second strong pair]], y [b]); weak corruption rate 0.1 (:75), strong = corruption_rate;
+    two_strong for CoMatch (trainers/evaluate.py:53)."""
+
+    def __init__(self, images, table, labels, img_size: int, target: str = "dvm", corruption_rate: float = 0.3, two_strong: bool = False,
+                 device="cuda", seed: int = 2022):
+        self.images = images.to(device)
+        self.table = torch.as_tensor(table, dtype=torch.float32).to(device)
+        self.labels = torch.as_tensor(labels, dtype=torch.int64).to(device)
+        self.weak_corrupt = TabularCorruptor(self.table, 0.1, device, seed)
+        self.strong_corrupt = TabularCorruptor(self.table, corruption_rate, device, seed + 7)
+        self.weak = ImageAugmenter(img_size, target, 1.0, seed + 1, kind="weak")
+        self.strong = ImageAugmenter(img_size, target, 1.0, seed + 2, kind="strong")
+        self.two_strong = bool(two_strong)
+
+    def __len__(self):
+        return len(self.labels)
+
+    def __call__(self, index: torch.Tensor):
+        index = torch.as_tensor(index).to(self.table.device, torch.int64)
+        clean = self.table.index_select(0, index)
+        src = self.images.index_select(0, index)
+        views = [(self.weak(src, want_orig=False)[0], self.weak_corrupt(clean))]
+        for _ in range(2 if self.two_strong else 1):
+            views.append((self.strong(src, want_orig=False)[0], self.strong_corrupt(clean)))
+        return views, self.labels.index_select(0, index)

@@ -187,6 +187,84 @@ __global__ __launch_bounds__(256) void aug_blur_kernel(AugArgs p, const float* _
   o[0] = acc[0]; o[plane] = acc[1]; o[2 * plane] = acc[2];
 }
 
+// ---------------------------------------------------------------- rotation (utils/utils.py:82,97,112,170: A.Rotate(limit) / RandomRotation)
+// Whole source image rotated by angle[b] degrees (counter-clockwise, like cv2.getRotationMatrix2D) about its centre
+// ((W-1)/2, (H-1)/2), same size: every output pixel samples the source bilinearly at its back-rotated position; positions
+// outside the image are mirrored without repeating the edge pixel (cv2.BORDER_REFLECT_101, albumentations' default).
+// angle 0 copies.  -> float CHW [B,3,H,W] scaled by `scale`.
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  const int period = 2 * n - 2;
+  i = i % period;
+  if (i < 0) i += period;
+  return i < n ? i : period - i;
+}
+
+__global__ __launch_bounds__(256) void aug_rotate_kernel(AugArgs p, const float* __restrict__ angle, float* __restrict__ dst) {
+  const int b = blockIdx.y;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= p.H * p.W) return;
+  const int y = pix / p.W, x = pix - y * p.W;
+  const float th = angle[b] * 0.017453292519943295f;
+  const float ca = cosf(th), sa = sinf(th);
+  const float cx = 0.5f * (float)(p.W - 1), cy = 0.5f * (float)(p.H - 1);
+  const float dx = (float)x - cx, dy = (float)y - cy;
+  const float fx = ca * dx - sa * dy + cx, fy = sa * dx + ca * dy + cy;   // inverse of M = [[ca, sa], [-sa, ca]] about the centre
+  const float flx = floorf(fx), fly = floorf(fy);
+  const float lx = fx - flx, ly = fy - fly;
+  const int x0 = reflect101((int)flx, p.W), x1 = reflect101((int)flx + 1, p.W);
+  const int y0 = reflect101((int)fly, p.H), y1 = reflect101((int)fly + 1, p.H);
+  float a[3], bb[3], c[3], d[3];
+  aug_fetch(p, b, y0, x0, a); aug_fetch(p, b, y0, x1, bb); aug_fetch(p, b, y1, x0, c); aug_fetch(p, b, y1, x1, d);
+  const long plane = (long)p.H * p.W;
+  float* o = dst + (long)b * 3 * plane + pix;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float t0 = a[k] + lx * (bb[k] - a[k]), t1 = c[k] + lx * (d[k] - c[k]);
+    o[k * plane] = (t0 + ly * (t1 - t0)) * p.scale;
+  }
+}
+
+// ---------------------------------------------------------------- hue (+ grayscale after it): ColorJitter(hue=0.1) of the strong views
+// torchvision's float adjust_hue on CHW images in [0, 1], in place: RGB -> HSV, h <- (h + hue[b]) mod 1, HSV -> RGB; then
+// (gray[b] != 0) the 3-channel grey image (RandomGrayscale / ToGray come after the colour jitter, utils/utils.py:225-226).
+__global__ __launch_bounds__(256) void aug_hue_kernel(float* __restrict__ img, const float* __restrict__ hue, const float* __restrict__ gray,
+                                                       int H, int W) {
+  const int b = blockIdx.y;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= H * W) return;
+  const long plane = (long)H * W;
+  float* q = img + (long)b * 3 * plane + pix;
+  float v[3] = {q[0], q[plane], q[2 * plane]};
+  const float hf = hue ? hue[b] : 0.f;
+  if (hf != 0.f) {
+    const float r = v[0], g = v[1], bl = v[2];
+    const float maxc = fmaxf(r, fmaxf(g, bl)), minc = fminf(r, fminf(g, bl));
+    const bool eq = maxc == minc;
+    const float cr = maxc - minc;
+    const float s = cr / (eq ? 1.f : maxc), dv = eq ? 1.f : cr;
+    const float rc = (maxc - r) / dv, gc = (maxc - g) / dv, bc = (maxc - bl) / dv;
+    float h = maxc == r ? (bc - gc) : (maxc == g ? 2.f + rc - bc : 4.f + gc - rc);
+    h = fmodf(h / 6.f + 1.f, 1.f);
+    h = h + hf;
+    h = h - floorf(h);                                   // python's % 1.0
+    const float h6 = h * 6.f;
+    const float fi = floorf(h6), f = h6 - fi;
+    const int i = ((int)fi) % 6;
+    const float pp = clamp01(maxc * (1.f - s)), qq = clamp01(maxc * (1.f - f * s)), tt = clamp01(maxc * (1.f - (1.f - f) * s));
+    switch (i) {
+      case 0: v[0] = maxc; v[1] = tt; v[2] = pp; break;
+      case 1: v[0] = qq; v[1] = maxc; v[2] = pp; break;
+      case 2: v[0] = pp; v[1] = maxc; v[2] = tt; break;
+      case 3: v[0] = pp; v[1] = qq; v[2] = maxc; break;
+      case 4: v[0] = tt; v[1] = pp; v[2] = maxc; break;
+      default: v[0] = maxc; v[1] = pp; v[2] = qq; break;
+    }
+  }
+  if (gray && gray[b] != 0.f) { const float g2 = gray_of(v); v[0] = v[1] = v[2] = g2; }
+  q[0] = v[0]; q[plane] = v[1]; q[2 * plane] = v[2];
+}
+
 // ---------------------------------------------------------------- C ABI
 extern "C" int stil_tab_corrupt(const float* clean, const float* marginal, const int* idx, const int* pos, float* out,
                                 int B, int n_cols, int n_rows, int k, void* stream) {
@@ -244,6 +322,22 @@ extern "C" int stil_aug_blur(const unsigned char* src_u8, const float* src_f32, 
   hipLaunchKernelGGL(aug_blur_kernel, grid, dim3(256), 0, (hipStream_t)stream, p, sigma, (const float*)nullptr, tmp, ksize, 0);
   STIL_LAUNCH_CHECK();
   hipLaunchKernelGGL(aug_blur_kernel, grid, dim3(256), 0, (hipStream_t)stream, p, sigma, (const float*)tmp, out, ksize, 1);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" int stil_aug_rotate(const unsigned char* src_u8, const float* src_f32, const float* angle, float* out, int B, int H, int W,
+                               float scale, void* stream) {
+  STIL_REQUIRE((src_u8 != nullptr) != (src_f32 != nullptr) && angle && out && B > 0 && H > 0 && W > 0, "stil_aug_rotate: bad arguments");
+  AugArgs p{src_u8, src_f32, nullptr, nullptr, nullptr, nullptr, nullptr, H, W, 1, scale};
+  hipLaunchKernelGGL(aug_rotate_kernel, dim3(cdiv((long)H * W, 256), B), dim3(256), 0, (hipStream_t)stream, p, angle, out);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+extern "C" int stil_aug_hue(float* img, const float* hue, const float* gray, int B, int H, int W, void* stream) {
+  STIL_REQUIRE(img && (hue || gray) && B > 0 && H > 0 && W > 0, "stil_aug_hue: bad arguments");
+  hipLaunchKernelGGL(aug_hue_kernel, dim3(cdiv((long)H * W, 256), B), dim3(256), 0, (hipStream_t)stream, img, hue, gray, H, W);
   STIL_LAUNCH_CHECK();
   return STIL_OK;
 }

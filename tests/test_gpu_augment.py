@@ -158,3 +158,114 @@ def test_batch_builder_feeds_the_training_step():
     m.prototypes.copy_(F.normalize(torch.randn(5, 128, generator=g)).cuda())
     loss = train_step(m, StilAdam(m.flat, lr=1e-3), {"l": bl, "u": bu})
     assert bool(torch.isfinite(loss))
+
+
+def _reflect101(i, n):
+    period = 2 * n - 2
+    i = i % period
+    return torch.where(i < n, i, period - i)
+
+
+def test_rotate_matches_bilinear_reflect101_restatement():
+    """stil_aug_rotate against a float64 restatement of A.Rotate's geometry (cv2.getRotationMatrix2D about ((W-1)/2, (H-1)/2),
+    bilinear, BORDER_REFLECT_101); 0 degrees copies, 90 / 180 degrees on a square image are exact permutations."""
+    from stil_tta_amd.augment import rotate
+    g = torch.Generator().manual_seed(8)
+    img = torch.randint(0, 256, (4, 37, 53, 3), generator=g, dtype=torch.uint8)
+    ang = torch.tensor([0.0, 17.5, -44.0, 180.0])
+    got = rotate(img.cuda(), ang).cpu().double()
+    src = img.permute(0, 3, 1, 2).double() / 255.0
+    H, W = 37, 53
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float64), torch.arange(W, dtype=torch.float64), indexing="ij")
+    for b in range(4):
+        th = float(ang[b]) * np.pi / 180.0
+        ca, sa = np.cos(th), np.sin(th)
+        cx, cy = (W - 1) / 2, (H - 1) / 2
+        fx = ca * (xs - cx) - sa * (ys - cy) + cx
+        fy = sa * (xs - cx) + ca * (ys - cy) + cy
+        x0, y0 = torch.floor(fx), torch.floor(fy)
+        lx, ly = fx - x0, fy - y0
+        X0, X1 = _reflect101(x0.long(), W), _reflect101(x0.long() + 1, W)
+        Y0, Y1 = _reflect101(y0.long(), H), _reflect101(y0.long() + 1, H)
+        s = src[b]
+        ref = (s[:, Y0, X0] * (1 - lx) + s[:, Y0, X1] * lx) * (1 - ly) + (s[:, Y1, X0] * (1 - lx) + s[:, Y1, X1] * lx) * ly
+        tol = 1e-6 if b == 0 else 2e-4           # float32 sin / cos move the sample position by up to ~1e-5 pixels
+        assert float((got[b] - ref).abs().max()) <= tol, (b, float((got[b] - ref).abs().max()))
+    assert float((got[0] - src[0]).abs().max()) <= 1e-7
+    sq = torch.rand(1, 3, 16, 16, generator=g)
+    r90 = rotate(sq.cuda(), [90.0]).cpu()
+    assert float((r90[0] - torch.rot90(sq[0], 1, dims=(1, 2))).abs().max()) <= 2e-6      # counter-clockwise
+
+
+def test_hue_matches_torchvision_float_formulas():
+    """stil_aug_hue against a restatement of torchvision's _rgb2hsv / _hsv2rgb / adjust_hue (float tensors); hue 0 is the
+    identity, grey pixels do not move, and the grey conversion comes after the hue shift."""
+    from stil_tta_amd.augment import adjust_hue_
+    g = torch.Generator().manual_seed(9)
+    img = torch.rand(3, 3, 20, 24, generator=g)
+    img[0, :, :4] = img[0, :1, :4]            # some exactly grey pixels
+    hue = torch.tensor([0.07, -0.1, 0.0])
+    gray = torch.tensor([0.0, 1.0, 0.0])
+    got = adjust_hue_(img.clone().cuda(), hue, gray).cpu()
+
+    def tv_hue(x, hf):
+        r, gg, b = x.unbind(0)
+        maxc, minc = x.max(0).values, x.min(0).values
+        eqc = maxc == minc
+        cr = maxc - minc
+        ones = torch.ones_like(maxc)
+        s = cr / torch.where(eqc, ones, maxc)
+        crd = torch.where(eqc, ones, cr)
+        rc, gc, bc = (maxc - r) / crd, (maxc - gg) / crd, (maxc - b) / crd
+        hr = (maxc == r) * (bc - gc)
+        hg = ((maxc == gg) & (maxc != r)) * (2.0 + rc - bc)
+        hb = ((maxc != gg) & (maxc != r)) * (4.0 + gc - rc)
+        h = torch.fmod((hr + hg + hb) / 6.0 + 1.0, 1.0)
+        h = (h + hf) % 1.0
+        i = torch.floor(h * 6.0)
+        f = h * 6.0 - i
+        i = i.to(torch.int32) % 6
+        v = maxc
+        p = torch.clamp(v * (1.0 - s), 0.0, 1.0)
+        q = torch.clamp(v * (1.0 - f * s), 0.0, 1.0)
+        t = torch.clamp(v * (1.0 - (1.0 - f) * s), 0.0, 1.0)
+        a1 = torch.stack((v, q, p, p, t, v)); a2 = torch.stack((t, v, v, q, p, p)); a3 = torch.stack((p, p, t, v, v, q))
+        sel = torch.nn.functional.one_hot(i.long(), 6).permute(2, 0, 1).to(x.dtype)
+        return torch.stack(((a1 * sel).sum(0), (a2 * sel).sum(0), (a3 * sel).sum(0)))
+
+    ref0 = tv_hue(img[0], 0.07)
+    ref1 = tv_hue(img[1], -0.1)
+    ref1 = (0.2989 * ref1[0] + 0.587 * ref1[1] + 0.114 * ref1[2]).expand(3, -1, -1)
+    assert float((got[0] - ref0).abs().max()) <= 3e-6 and float((got[1] - ref1).abs().max()) <= 3e-6
+    assert float((got[2] - img[2]).abs().max()) == 0.0
+    assert float((got[0, :, :4] - img[0, :, :4]).abs().max()) <= 1e-6
+
+
+def test_match_batch_builders_feed_a_comatch_step():
+    """EvalTrainBatchBuilder + StrongWeakBatchBuilder emit the batches of trainers/evaluate.py:50-83; a CoMatch step on them
+    (cardiac transform family: rotation, no grayscale) runs and is finite."""
+    from stil_tta_amd import CoMatch
+    from stil_tta_amd.augment import EvalTrainBatchBuilder, StrongWeakBatchBuilder
+    from stil_tta_amd.driver import train_step
+    from stil_tta_amd.flat import StilAdam
+    g = torch.Generator().manual_seed(4)
+    N, fl = 48, [3, 4] + [1] * 8
+    imgs = torch.rand(N, 3, 80, 72, generator=g)          # cardiac images are float [0,1] (convert_to_ts_01)
+    table = torch.cat([torch.randint(0, 3, (N, 1), generator=g).float(), torch.randint(0, 4, (N, 1), generator=g).float(), torch.randn(N, 8, generator=g)], 1)
+    labels = torch.randint(0, 2, (N,), generator=g)
+    lab = EvalTrainBatchBuilder(imgs[:8], table[:8], labels[:8], 64, "CAD", 0.3, 0.8)
+    unl = StrongWeakBatchBuilder(imgs[8:], table[8:], labels[8:], 64, "CAD", 0.3, two_strong=True)
+    (x_l, t_l), y_l, idx = lab(torch.tensor([0, 5]))
+    views, y_u = unl(torch.randperm(40, generator=g)[:14])
+    assert x_l.shape == (2, 3, 64, 64) and t_l.shape == (2, 10) and idx.tolist() == [0, 5] and len(views) == 3
+    w, s0, s1 = views
+    assert w[0].shape == s0[0].shape == s1[0].shape == (14, 3, 64, 64) and w[1].shape == (14, 10)
+    clean = table[8:].cuda()
+    assert all(float(v[0].min()) >= 0.0 and float(v[0].max()) <= 1.0 + 1e-6 for v in views)   # the post-crop blur may round 1 ulp above 1
+    assert not torch.equal(s0[0], s1[0])                                           # two independent strong views
+    torch.manual_seed(0)
+    m = CoMatch(dict(model="resnet18", embedding_dim=512, field_lengths=fl, num_classes=2, start_epoch=0, batch_size=16, img_size=64, K=40,
+                     co_threshold=0.5, contrast_th=0.5))
+    m.setup_device("cuda"); m.train(); m.current_epoch = 1
+    loss = train_step(m, StilAdam(m.flat, lr=1e-3), {"l": ((x_l, t_l), y_l, idx), "u": (views, y_u)})
+    assert bool(torch.isfinite(loss)) and int(m.model.queue_ptr_s) == 14
