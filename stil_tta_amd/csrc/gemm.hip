@@ -179,8 +179,12 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNTArgs& p, f32x16 (&a
 // PLAIN: the A operand is a plain row-major matrix (1x1 convolution with stride 1 / no padding, nn.Linear) and the output
 // map is the identity: the (n, oy, ox) row decode, the tap walk and the output re-map -- ~500 integer instructions per
 // workgroup, as many as the MFMAs of a K = 64 tile take -- are compiled out.
+// amdgpu_waves_per_eu: a register budget for the instantiations the step spends its time in -- 64x64 tiles at 6 waves per SIMD
+// (the conv-gather two-level kernel would otherwise take 88 registers = 5 waves), plain 128x64 two-level at 4 (120 instead of
+// 140 registers); none of them spills (checked in the ISA: private_segment_fixed_size 0).
 template <int TM, int TN, int BK, bool VEC, bool ACC2 = false, bool PLAIN = false>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BK == 16 && VEC) ? (TM * TN == 1 ? 6 : ((TM * TN == 2 && ACC2 && PLAIN) ? 4 : 1)) : 1)))
+void gemm_nt_kernel(GemmNTArgs p) {
   constexpr int BM = 64 * TM, BN = 64 * TN, LS = BK + 4;   // LS = 20 / 36: conflict-free ds_read_b128 (i*LS mod 64 distinct)
   constexpr int KQ = BK / 4, RP = 256 / KQ;                 // float4 per tile row, tile rows per load pass
   constexpr int RA = BM / RP, RB = BN / RP;
