@@ -48,7 +48,7 @@ int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, 
                  const float* bias, const float* sub, const float* scale, const float* shift, const float* resid,
                  int ldr, float* pre, int act, float alpha, float* colstats, int tune, void* stream);
 /* `tune` (0 = automatic; otherwise for A/B measurements) = variant + 100 * bk32 + 1000 * acc2:
- *   variant  block tile: 22 = 128x128, 21 = 128x64, 11 = 64x64 (0: chosen from M, N);
+ *   variant  block tile: 22 = 128x128, 21 = 128x64, 11 = 64x64 (0: automatic = 64x64, the fastest on every shape of the step);
  *   bk32     1 = 32-deep LDS k-tiles instead of 16;
  *   acc2     two-level accumulation (partial chains of 64 products added to a master accumulator, ~ATen-CPU's
  *            rounding noise for long reductions): 0 = for K >= 512, 1 = never, 2 = always.

@@ -609,10 +609,9 @@ static int gemm_nt_attr() {
 extern "C" int stil_gemm_nt_variant(int M, int N, int tune) {
   const int forced = tune % 100;
   if (forced == 11 || forced == 21 || forced == 22) return forced;
-  // measured (tests/tools/gemm_bench.py): fp32 MFMA is slow enough that 64x64 / 128x64 block tiles lose nothing to
-  // 128x128 in operand reuse and win on occupancy + tile quantization over 256 CUs.
-  if (N <= 64) return M <= 4096 ? 11 : 21;
-  if (N >= 1024 && M >= 8192) return 21;
+  // measured (tests/tools/gemm_bench.py, profiles/r02t-u): with 6 waves per SIMD the 64x64 tile is at least as fast as
+  // 128x64 / 128x128 on every shape of the step (occupancy + tile quantisation over 256 CUs outweigh operand reuse).
+  (void)M; (void)N;
   return 11;
 }
 
