@@ -36,7 +36,8 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     with pytest.raises(RuntimeError, match="multiple of 4"):
         L.ema_update(ctypes.c_void_p(16), ctypes.c_void_p(32), 6, 0.9, None)
     assert L.wgrad_workspace_bytes(1 << 20, 64, 576, 0) > 0
-    assert L.gemm_nt_variant(50176, 1024, 0) == 21 and L.gemm_nt_variant(256, 286, 0) == 11 and L.gemm_nt_variant(802816, 64, 0) == 21 and L.gemm_nt_variant(256, 286, 22) == 22
+    assert L.gemm_nt_variant(50176, 1024, 0) == 11 and L.gemm_nt_variant(256, 286, 0) == 11 and L.gemm_nt_variant(802816, 64, 21) == 21 and L.gemm_nt_variant(256, 286, 22) == 22
+    assert L.gemm_nt_tile_rows(802816, 64, 0) == 64 and L.gemm_nt_tile_rows(802816, 64, 21) == 128
 
 
 def test_ops_refuse_cpu_tensors_no_fallback():
