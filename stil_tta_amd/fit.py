@@ -94,12 +94,10 @@ class EarlyStopping:
 
 # ------------------------------------------------------------------------------------------ checkpoint I/O
 def adam_state_dict(model, optimizer) -> dict:
-    """torch.optim.Adam.state_dict() layout over the reference's six parameter groups (STiLModel.py:563-570), read out of
-    the flat slabs: parameter ids follow model, projector_imaging, projector_tabular, projector_multimodal, CLUB_imaging,
-    CLUB_tabular -- the order of FlatState.tensors."""
+    """torch.optim.Adam.state_dict() layout over the reference's parameter groups (model.optimizer_groups(): six for STiL,
+    STiLModel.py:563-570; `[self.model]` for the baselines, e.g. MMatch.py:385-387), read out of the flat slabs."""
     flat = model.flat
-    groups_of = [model.model, model.projector_imaging, model.projector_tabular, model.projector_multimodal,
-                 model.CLUB_imaging, model.CLUB_tabular]
+    groups_of = model.optimizer_groups()
     g = optimizer.param_groups[0]
     steps = flat.steps.cpu()
     state, groups, pid = {}, [], 0
@@ -108,11 +106,11 @@ def adam_state_dict(model, optimizer) -> dict:
     for mod in groups_of:
         ids = []
         for p in mod.parameters():
-            i = off[id(p)]
+            i = off.get(id(p))          # None: a frozen copy inside the group (the baselines' momentum encoders): listed, no state
             o = p.data_ptr() - flat.params.data_ptr()
             o //= 4
             n = p.numel()
-            if int(steps[i]) > 0:
+            if i is not None and int(steps[i]) > 0:
                 state[pid] = {"step": torch.tensor(float(steps[i])), "exp_avg": flat.exp_avg[o:o + n].view(p.shape).cpu().clone(),
                               "exp_avg_sq": flat.exp_avg_sq[o:o + n].view(p.shape).cpu().clone()}
             ids.append(pid)
@@ -123,8 +121,7 @@ def adam_state_dict(model, optimizer) -> dict:
 
 def load_adam_state_dict(model, optimizer, sd: dict) -> None:
     flat = model.flat
-    order = [p for mod in (model.model, model.projector_imaging, model.projector_tabular, model.projector_multimodal,
-                           model.CLUB_imaging, model.CLUB_tabular) for p in mod.parameters()]
+    order = [p for mod in model.optimizer_groups() for p in mod.parameters()]
     off = {id(t): i for i, t in enumerate(flat.tensors)}
     steps = torch.zeros_like(flat.steps, device="cpu")
     flat.exp_avg.zero_()

@@ -130,6 +130,9 @@ class _MatchBase(STiLModel):
         self.flat = FlatState(self.student, self.teacher, [], device)
         return self
 
+    def optimizer_groups(self):
+        return [self.model]   # Adam([{'params': self.model.parameters()}]): student and (frozen) momentum copy -- CoMatch.py:238-240
+
     def _to_dev(self, x, dev):
         if self.student.multimodal:
             return (x[0].to(dev, torch.float32).contiguous(), x[1].to(dev, torch.float32).contiguous())

@@ -141,6 +141,9 @@ class MMatch(STiLModel):
         self._ptr = None
         return super().load_state_dict(sd, strict)
 
+    def optimizer_groups(self):
+        return [self.model]   # Adam([{'params': self.model.parameters()}]) -- MMatch.py:385-387
+
     def forward(self, x):
         return self.model.run(x, self.training)
 
@@ -388,6 +391,7 @@ class CoTraining(STiLModel):
                          y_hat_i_e=yi_e, y_hat_t_e=yt_e, pseudo_label_i=pl_i, pseudo_label_t=pl_t, mask_i=mask_i, mask_t=mask_t)
         return loss
 
+    optimizer_groups = MMatch.optimizer_groups
     training_epoch_end = MMatch.training_epoch_end
     on_train_epoch_end = MMatch.training_epoch_end   # the reference uses the newer hook name (CoTraining.py:175)
     validation_step = MMatch.validation_step

@@ -255,6 +255,10 @@ class STiLModel(_Base):
             raise ValueError('Valid schedulers are "cosine" and "anneal"')  # STiLModel.py:587
         return {"optimizer": opt, "lr_scheduler": sched}
 
+    def optimizer_groups(self):
+        """The modules whose parameters form the reference optimizer's param_groups, in order (STiLModel.py:563-570)."""
+        return [self.model, self.projector_imaging, self.projector_tabular, self.projector_multimodal, self.CLUB_imaging, self.CLUB_tabular]
+
     def grad_signature(self):
         """What decides which parameters receive gradients in backward (comm.GradExchange learns one plan per value)."""
         return (self.current_epoch > self.hp.start_epoch, bool(self.training))

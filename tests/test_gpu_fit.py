@@ -173,3 +173,58 @@ def test_optimizer_state_layout_equals_the_references_adam():
     assert [float(osd["state"][i]["step"]) if i in osd["state"] else 0.0 for i in range(len(order))] == fx["steps"].tolist()
     for i in np.nonzero(has)[0][:5]:
         assert tuple(osd["state"][int(i)]["exp_avg"].shape) == tuple(order[int(i)].shape)
+
+
+class _Index:
+    """DataLoader stand-in over a device batch builder: yields builder(indices) for consecutive index chunks."""
+
+    def __init__(self, builder, bs):
+        self.b, self.bs = builder, bs
+
+    def __len__(self):
+        return len(self.b) // self.bs
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self.b(torch.arange(i * self.bs, (i + 1) * self.bs))
+
+
+@pytest.mark.parametrize("algo", ["SimMatch", "MMatch"])
+def test_fit_and_checkpoint_of_the_baselines(tmp_path, algo):
+    """fit -> best checkpoint (one Adam param_group over `model`, frozen momentum copy listed without state) -> reload -> test,
+    for a Match baseline fed by the device batch builders and for MMatch fed by the contrastive builder."""
+    import stil_tta_amd
+    from stil_tta_amd import fit as F
+    from stil_tta_amd.augment import ContrastiveBatchBuilder, EvalTrainBatchBuilder, StrongWeakBatchBuilder
+    li, lt, ly = _data(8, 1)
+    ui, ut, uy = _data(56, 2)
+    vi, vt, vy = _data(40, 3)
+    hp = dict(model="resnet18", embedding_dim=512, field_lengths=FL, num_classes=3, batch_size=16, target="dvm", start_epoch=0, lr_eval=1e-3,
+              scheduler="anneal", warmup_epochs=1, max_epochs=6, img_size=64, DA=True)
+    if algo == "SimMatch":
+        loaders = {"l": _Index(EvalTrainBatchBuilder(li, lt, ly, 64, "dvm", 0.3, 0.8), 2),
+                   "u": _Index(StrongWeakBatchBuilder(ui, ut, uy, 64, "dvm", 0.3), 14)}
+        make = lambda: stil_tta_amd.SimMatch(dict(hp, K=8, sim_threshold=0.4))  # noqa: E731
+    else:
+        loaders = {"l": _Index(ContrastiveBatchBuilder(li, lt, ly, 64, "dvm", 0.3, 0.95, labelled=True), 2),
+                   "u": _Index(ContrastiveBatchBuilder(ui, ut, uy, 64, "dvm", 0.3, 0.95, labelled=False), 14)}
+        make = lambda: stil_tta_amd.MMatch(dict(hp, th1=0.4, alpha=1.0))  # noqa: E731
+    val = _Val(vi, vt, vy, 16)
+    torch.manual_seed(0)
+    m = make()
+    out = F.fit(m, loaders, val, max_epochs=3, eval_metric="acc", logdir=str(tmp_path), verbose=False, prefetch=False)
+    assert out["stopped"] == "max_epochs" and out["global_step"] == 3 * 4 and os.path.exists(out["checkpoint"])
+    ck = torch.load(out["checkpoint"], map_location="cpu", weights_only=False)
+    groups = ck["optimizer_states"][0]["param_groups"]
+    assert len(groups) == 1 and len(groups[0]["params"]) == len(list(m.model.parameters()))
+    st = ck["optimizer_states"][0]["state"]
+    n_train = sum(1 for p in m.model.parameters() if p.requires_grad)
+    assert 50 < len(st) <= n_train and max(float(v["step"]) for v in st.values()) == ck["global_step"]
+    torch.manual_seed(1)
+    m2 = make()
+    m2.setup_device("cuda")
+    F.load_checkpoint(out["checkpoint"], m2, m2.configure_optimizers()["optimizer"])
+    got = F.validate(m2, val)
+    assert abs(got["eval.val.acc"] - out["best_score"]) < 1e-7
+    res = F.test(m2, val, ckpt_path=out["checkpoint"])
+    assert abs(res["test.acc"] - out["best_score"]) < 1e-7
