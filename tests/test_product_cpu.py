@@ -333,5 +333,10 @@ def test_module_keeps_its_epoch_and_log_shim_when_lightning_is_importable(tmp_pa
             "m.current_epoch = 7; assert m.current_epoch == 7; m.log('x', torch.tensor(1.0)); assert 'x' in m.logged; m.print('ok'); "
             "T = type('T', (), dict(current_epoch=11, world_size=2)); m.trainer = T(); assert m.current_epoch == 11; "
             "\ntry:\n    m.configure_optimizers(); raise SystemExit('Lightning DDP must be refused')\nexcept NotImplementedError:\n    pass\n"
+            "import stil_tta_amd as S\n"
+            "hp = dict(model='resnet18', embedding_dim=512, field_lengths=[3, 1], num_classes=3, batch_size=8, K=8, DA=True)\n"
+            "for cls in (S.MMatch, S.CoTraining, S.CoMatch, S.SimMatch, S.FreeMatch):\n"
+            "    b = cls(dict(hp)); assert isinstance(b, M.pl.LightningModule); b.current_epoch = 3; assert b.current_epoch == 3\n"
+            "    b.log('y', torch.tensor(2.0)); assert 'y' in b.logged and len(b.optimizer_groups()) == 1\n"
             % (str(tmp_path), ROOT))
     subprocess.run([sys.executable, "-c", code], check=True)
