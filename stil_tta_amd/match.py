@@ -23,7 +23,7 @@ from ._lib import lib
 from .flat import FlatState
 from .modules import ResNet, TabularTransformerEncoder
 from .ops import _p, _stream
-from .stil_model import _HAVE_PL, STiLModel, _as_namespace, _Base
+from .stil_model import _HAVE_PL, STiLModel, _as_namespace, _Base, load_tip_weights
 
 
 def _world():
@@ -65,6 +65,9 @@ class MatchBackbone(nn.Module):
             self.head = nn.Sequential(nn.Linear(E, E), nn.ReLU(inplace=True), nn.Linear(E, Dp))
         else:
             raise ValueError(f"Unknown eval_datatype {hp.eval_datatype}")
+        if getattr(hp, "checkpoint", None):   # TIP pre-training (multimodal_backbone.py:64-82; comatch_model.py:60-73 for the image-only encoder)
+            load_tip_weights(hp, [(self.encoder_imaging, "encoder_imaging."), (self.encoder_tabular, "encoder_tabular.")] if self.multimodal
+                             else [(self.backbone, "encoder_imaging.")])
 
     def run(self, x, train: bool):
         lin = lambda t, m, act=0: ops.linear(t, m.weight, m.bias, act)  # noqa: E731

@@ -20,7 +20,7 @@ from ._lib import lib
 from .flat import FlatState
 from .modules import ResNet, TabularTransformerEncoder
 from .ops import _p, _stream
-from .stil_model import _HAVE_PL, STiLModel, _as_namespace, _Base
+from .stil_model import _HAVE_PL, STiLModel, _as_namespace, _Base, load_tip_weights
 
 BANK = 640  # MMatch.py:52
 
@@ -43,6 +43,8 @@ class MultimodalBackbone(nn.Module):
         self.classifier_multimodal = nn.Linear(hp.projection_dim, hp.num_classes)
         self.classifier_imaging = nn.Linear(hp.embedding_dim, hp.num_classes)
         self.classifier_tabular = nn.Linear(Dt, hp.num_classes)
+        if getattr(hp, "checkpoint", None):   # TIP pre-training: both encoders (Multimodal_model.py:62-81)
+            load_tip_weights(hp, [(self.encoder_imaging, "encoder_imaging."), (self.encoder_tabular, "encoder_tabular.")])
 
     def run(self, x, train: bool):
         """-> out_m, out_i, out_t, x_m  (Multimodal_model.py:114-122)"""
@@ -74,6 +76,10 @@ class MultimodalBackboneSAINT(nn.Module):
         self.classifier_imaging = nn.Linear(hp.embedding_dim, hp.num_classes)
         self.classifier_tabular = nn.Linear(Dt, hp.num_classes)
         register_saint_meta(self, cats)
+        if getattr(hp, "checkpoint_SAINT", None):   # Multimodal_model_SAINT.py:137-139
+            self.encoder_tabular.load_state_dict(torch.load(hp.checkpoint_SAINT, map_location="cpu", weights_only=False))
+        if getattr(hp, "checkpoint", None):         # TIP: the image encoder only (:64-83)
+            load_tip_weights(hp, [(self.encoder_imaging, "encoder_imaging.")])
 
     def run(self, x, train: bool, masks=None):
         """-> out_m, out_i, out_t, x_m  (Multimodal_model_SAINT.py:187-195); masks: the two feed-forward dropout keep-masks."""

@@ -61,6 +61,25 @@ def _as_namespace(hp) -> SimpleNamespace:
     return SimpleNamespace(**d)
 
 
+def load_tip_weights(hp, pairs):
+    """`load_weights` of the reference's backbones (STiLModel_backbone.py:108-115, Multimodal_model.py:96-112,
+    multimodal_backbone.py:97-116, comatch_model.py:102-110): every (module, prefix) pair takes the `prefix*` entries of the
+    TIP checkpoint `hp.checkpoint` (projection heads / prototypes skipped, strict); finetune_strategy 'frozen' stops their
+    gradients."""
+    ck = torch.load(hp.checkpoint, map_location="cpu", weights_only=False)
+    sd = ck["state_dict"]
+    if hp.pretrained_model != "TIP":
+        raise ValueError(f"Unknown pretrain model: {hp.pretrained_model}")  # STiLModel_backbone.py:89-90
+    if hp.finetune_strategy not in ("frozen", "trainable"):
+        raise ValueError(f"Unknown finetune strategy {hp.finetune_strategy}")
+    for mod, prefix in pairs:
+        sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix) and "projection_head" not in k and "prototypes" not in k}
+        mod.load_state_dict(sub, strict=True)
+        if hp.finetune_strategy == "frozen":
+            for p in mod.parameters():
+                p.requires_grad = False
+
+
 class SimCLRProjectionHead(nn.Module):
     """lightly==1.2.22 SimCLRProjectionHead restated: Linear -> ReLU -> Linear under `.layers` (unpinned)."""
 
@@ -202,19 +221,10 @@ class STiLModel(_Base):
 
     def _load_tip_checkpoint(self, hp):
         """STiLModel_backbone.py:69-90,108-115: load encoder_imaging.* / encoder_tabular.* from a TIP checkpoint."""
-        ck = torch.load(hp.checkpoint, map_location="cpu", weights_only=False)
-        sd = ck["state_dict"]
-        if hp.pretrained_model != "TIP":
-            raise ValueError(f"Unknown pretrain model: {hp.pretrained_model}")  # STiLModel_backbone.py:89-90
         pairs = [(self.model.encoder_imaging, "encoder_imaging.")]
         if hp.tabular_encoder != "saint":  # the SAINT backbone takes only the image encoder from TIP (STiLModel_SAINT_backbone.py:74-76)
             pairs.append((self.model.encoder_tabular, "encoder_tabular."))
-        for mod, prefix in pairs:
-            sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix) and "projection_head" not in k and "prototypes" not in k}
-            mod.load_state_dict(sub, strict=True)
-            if hp.finetune_strategy == "frozen":
-                for p in mod.parameters():
-                    p.requires_grad = False
+        load_tip_weights(hp, pairs)
         if self.use_ema:
             self.ema.load_state_dict(self.model.state_dict())
 

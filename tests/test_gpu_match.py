@@ -257,3 +257,28 @@ def test_freematch_kernels_against_torch():
             ref.backward()
             assert abs(float(loss) - float(ref)) <= 2e-5 * (1 + abs(float(ref))), (R, K, which, float(loss), float(ref))
             assert float((zd.grad.cpu().double() - z64.grad).abs().max()) <= 2e-5 * (1e-3 + float(z64.grad.abs().max())), (R, K, which)
+
+
+def test_frozen_encoders_keep_their_weights_and_the_heads_still_train():
+    """finetune_strategy == 'frozen' (multimodal_backbone.py:70-76): the TIP encoders receive no gradient and do not move; the
+    projections / head / classifier do."""
+    import stil_tta_amd
+    from stil_tta_amd.driver import train_step
+    from stil_tta_amd.flat import StilAdam
+    hp = XO.default_hparams(**dict(GX.R18, K=40, contrast_th=0.3, co_threshold=0.3))
+    torch.manual_seed(0)
+    m = stil_tta_amd.CoMatch(dict(vars(hp)))
+    for enc in (m.model.encoder.encoder_imaging, m.model.encoder.encoder_tabular):
+        for p in enc.parameters():
+            p.requires_grad = False
+    m.setup_device("cuda"); m.train(); m.current_epoch = 2
+    before = {k: v.clone() for k, v in m.state_dict().items() if k.startswith("model.encoder.")}
+    batch = XO.synthetic_batch(hp, 16, seed=5, views=3)
+    dbatch = {"l": tuple(_dev(t) for t in batch["l"]), "u": (_dev(batch["u"][0]), batch["u"][1].cuda())}
+    loss = train_step(m, StilAdam(m.flat, lr=1e-2), dbatch)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(loss))
+    after = m.state_dict()
+    moved = {k for k, v in before.items() if v.is_floating_point() and not torch.equal(v, after[k])}
+    assert not any(("encoder_imaging" in k or "encoder_tabular" in k) and not ("running_" in k) for k in moved), sorted(moved)[:5]
+    assert {"model.encoder.head.2.weight", "model.encoder.classifier_multimodal.weight", "model.encoder.image_proj.weight"} <= moved

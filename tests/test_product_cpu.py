@@ -304,6 +304,23 @@ def test_checkpoint_loading_tip_and_saint(tmp_path):
     for k, v in saint_sd.items():
         assert torch.equal(got["model.encoder_tabular." + k], v) and torch.equal(got["ema.encoder_tabular." + k], v), k
     assert torch.equal(got["model.encoder_imaging.conv1.weight"], tip["state_dict"]["encoder_imaging.conv1.weight"])
+    # the baselines take the same TIP checkpoint (Multimodal_model.py:62-81, multimodal_backbone.py:64-82, comatch_model.py:60-73)
+    import stil_tta_amd as S
+    w_img, w_tab = tip["state_dict"]["encoder_imaging.conv1.weight"], tip["state_dict"]["encoder_tabular.cls_token"]
+    for cls, stu, tea, img in ((S.MMatch, "model.", None, "encoder_imaging."), (S.CoTraining, "model.", "ema.", "encoder_imaging."),
+                               (S.CoMatch, "model.encoder.", "model.m_encoder.", "encoder_imaging."), (S.SimMatch, "model.main.", "model.ema.", "encoder_imaging."),
+                               (S.FreeMatch, "model.main.", "model.ema.", "encoder_imaging.")):
+        b = cls(dict(base, checkpoint=str(pt), finetune_strategy="frozen", K=8, DA=True)).state_dict()
+        for pre in (stu, tea):
+            if pre is not None:
+                assert torch.equal(b[pre + img + "conv1.weight"], w_img) and torch.equal(b[pre + "encoder_tabular.cls_token"], w_tab), (cls.__name__, pre)
+    bi = S.CoMatch(dict(base, checkpoint=str(pt), eval_datatype="imaging", K=8))
+    assert torch.equal(bi.state_dict()["model.encoder.backbone.conv1.weight"], w_img) and torch.equal(bi.state_dict()["model.m_encoder.backbone.conv1.weight"], w_img)
+    assert all(p.requires_grad for p in bi.model.encoder.backbone.parameters())       # trainable is the default strategy
+    bs = S.CoTraining(dict(base, tabular_encoder="saint", checkpoint=str(pt), checkpoint_SAINT=str(ps), finetune_strategy="frozen"))
+    gs = bs.state_dict()
+    assert torch.equal(gs["model.encoder_imaging.conv1.weight"], w_img) and torch.equal(gs["ema.encoder_tabular.embeds.weight"], saint_sd["embeds.weight"])
+    assert not any(p.requires_grad for p in bs.model.encoder_imaging.parameters()) and all(p.requires_grad for p in bs.model.encoder_tabular.parameters())
 
 
 def test_module_keeps_its_epoch_and_log_shim_when_lightning_is_importable(tmp_path):
