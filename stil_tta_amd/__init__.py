@@ -19,4 +19,14 @@ class SemiDisCoPseudoSmooth(STiLModel):
         super().__init__(hp)
 
 
-__all__ = ["STiLModel", "SemiDisCoPseudoSmooth", "MMatch", "CoTraining", "CoMatch", "SimMatch", "FreeMatch", "lib", "build", "LIB_PATH"]
+def create_model(hparams):
+    """The `algorithm_name` dispatch of trainers/evaluate.py:142-166: the module the reference would build for these hparams."""
+    name = hparams["algorithm_name"] if isinstance(hparams, dict) else getattr(hparams, "algorithm_name", None)
+    table = {"STiL": STiLModel, "STiL_SAINT": SemiDisCoPseudoSmooth, "MMatch": MMatch, "SimMatch": SimMatch, "CoMatch": CoMatch,
+             "FreeMatch": FreeMatch, "CoTrain_Pseudo": CoTraining, "CoTrain_Pseudo_SAINT": CoTraining}
+    if name not in table:
+        raise ValueError(f"Algorithm name not found: {name!r} (one of {sorted(table)})")
+    return table[name](hparams)
+
+
+__all__ = ["create_model", "STiLModel", "SemiDisCoPseudoSmooth", "MMatch", "CoTraining", "CoMatch", "SimMatch", "FreeMatch", "lib", "build", "LIB_PATH"]

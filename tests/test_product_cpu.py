@@ -357,3 +357,18 @@ def test_module_keeps_its_epoch_and_log_shim_when_lightning_is_importable(tmp_pa
             "    b.log('y', torch.tensor(2.0)); assert 'y' in b.logged and len(b.optimizer_groups()) == 1\n"
             % (str(tmp_path), ROOT))
     subprocess.run([sys.executable, "-c", code], check=True)
+
+
+def test_create_model_follows_the_references_algorithm_dispatch():
+    """trainers/evaluate.py:142-166."""
+    import stil_tta_amd as S
+    hp = dict(model="resnet18", embedding_dim=512, field_lengths=[3, 1, 1], num_classes=3, batch_size=8, K=8, DA=True)
+    want = {"STiL": S.STiLModel, "STiL_SAINT": S.SemiDisCoPseudoSmooth, "MMatch": S.MMatch, "SimMatch": S.SimMatch, "CoMatch": S.CoMatch,
+            "FreeMatch": S.FreeMatch, "CoTrain_Pseudo": S.CoTraining, "CoTrain_Pseudo_SAINT": S.CoTraining}
+    for name, cls in want.items():
+        m = S.create_model(dict(hp, algorithm_name=name))
+        assert type(m) is cls, name
+    assert S.create_model(dict(hp, algorithm_name="CoTrain_Pseudo_SAINT")).saint and not S.create_model(dict(hp, algorithm_name="CoTrain_Pseudo")).saint
+    assert "encoder_tabular.transformer.layers.0.0.fn.fn.to_qkv.weight" in S.create_model(dict(hp, algorithm_name="STiL_SAINT")).model.state_dict()
+    with pytest.raises(ValueError):
+        S.create_model(dict(hp, algorithm_name="FixMatch"))
