@@ -324,3 +324,53 @@ class StrongWeakBatchBuilder:
         for _ in range(2 if self.two_strong else 1):
             views.append((self.strong(src, want_orig=False)[0], self.strong_corrupt(clean)))
         return views, self.labels.index_select(0, index)
+
+
+class IndexLoader:
+    """torch DataLoader(dataset, batch_size, shuffle=True) over a device batch builder: one epoch = a fresh permutation of the
+    builder's rows in chunks of `batch_size` (the last partial chunk is kept, like DataLoader's drop_last=False)."""
+
+    def __init__(self, builder, batch_size: int, shuffle: bool = True, seed: int = 2022, drop_last: bool = False):
+        self.builder, self.bs, self.shuffle, self.drop_last = builder, int(batch_size), bool(shuffle), bool(drop_last)
+        self.gen = torch.Generator().manual_seed(seed)
+
+    def __len__(self):
+        n = len(self.builder)
+        return n // self.bs if self.drop_last else (n + self.bs - 1) // self.bs
+
+    def __iter__(self):
+        n = len(self.builder)
+        order = torch.randperm(n, generator=self.gen) if self.shuffle else torch.arange(n)
+        for i in range(len(self)):
+            yield self.builder(order[i * self.bs:(i + 1) * self.bs])
+
+
+def semisl_loaders(hparams, labelled, unlabelled, device="cuda"):
+    """load_datasets_separate (trainers/evaluate.py:50-83) on data that is already in memory: labelled / unlabelled =
+    (images, table, labels) with images uint8 [N,H,W,3] or float [N,3,H,W].  Sets hparams.repeat_ratio (and hparams.K for
+    SimMatch) like the reference, splits the batch 1 : unlabelled_ratio, and returns {'l': loader, 'u': loader} of device batch
+    builders in the batch layout the selected algorithm consumes."""
+    from .fit import repeat_ratio, split_batch_size
+    get = (lambda k, d=None: hparams.get(k, d)) if isinstance(hparams, dict) else (lambda k, d=None: getattr(hparams, k, d))
+
+    def put(k, v):
+        if isinstance(hparams, dict):
+            hparams[k] = v
+        else:
+            setattr(hparams, k, v)
+
+    algo, seed = get("algorithm_name", "STiL"), int(get("seed", 2022))
+    common = dict(img_size=get("img_size"), target=get("target", "dvm"), corruption_rate=get("corruption_rate", 0.3), device=device)
+    (il, tl, yl), (iu, tu, yu) = labelled, unlabelled
+    if algo in ("CoMatch", "SimMatch", "FreeMatch"):
+        lab = EvalTrainBatchBuilder(il, tl, yl, eval_train_augment_rate=get("eval_train_augment_rate", 0.8), seed=seed, **common)
+        unl = StrongWeakBatchBuilder(iu, tu, yu, two_strong=(algo == "CoMatch"), seed=seed + 100, **common)
+        if algo == "SimMatch":
+            put("K", len(lab))
+    else:
+        lab = ContrastiveBatchBuilder(il, tl, yl, augmentation_rate=get("augmentation_rate", 0.95), labelled=True, seed=seed, **common)
+        unl = ContrastiveBatchBuilder(iu, tu, yu, augmentation_rate=get("augmentation_rate", 0.95), labelled=False, seed=seed + 100, **common)
+    ratio = int(get("unlabelled_ratio", 7))
+    put("repeat_ratio", repeat_ratio(len(unl), len(lab), ratio))
+    l_bs, u_bs = split_batch_size(int(get("batch_size")), ratio)
+    return {"l": IndexLoader(lab, l_bs, seed=seed + 1), "u": IndexLoader(unl, u_bs, seed=seed + 2)}

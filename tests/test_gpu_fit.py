@@ -228,3 +228,29 @@ def test_fit_and_checkpoint_of_the_baselines(tmp_path, algo):
     assert abs(got["eval.val.acc"] - out["best_score"]) < 1e-7
     res = F.test(m2, val, ckpt_path=out["checkpoint"])
     assert abs(res["test.acc"] - out["best_score"]) < 1e-7
+
+
+@pytest.mark.parametrize("algo", ["FreeMatch", "CoMatch", "STiL"])
+def test_create_model_semisl_loaders_and_fit(tmp_path, algo):
+    """The reference's evaluate() flow (trainers/evaluate.py:50-83,142-213) on in-memory data: create_model + semisl_loaders
+    (device batch builders, shuffled index loaders, repeat_ratio / K set on the hparams) + fit + test."""
+    import stil_tta_amd
+    from stil_tta_amd import fit as F
+    from stil_tta_amd.augment import semisl_loaders
+    li, lt, ly = _data(9, 1)
+    ui, ut, uy = _data(56, 2)
+    vi, vt, vy = _data(40, 3)
+    hp = dict(algorithm_name=algo, model="resnet18", embedding_dim=512, field_lengths=FL, num_classes=3, batch_size=16, target="dvm",
+              start_epoch=0, lr_eval=1e-3, scheduler="anneal", warmup_epochs=1, max_epochs=6, img_size=64, unlabelled_ratio=7, K=40,
+              th1=0.5, mi_dropout=False, co_threshold=0.4, contrast_th=0.4)
+    loaders = semisl_loaders(hp, (li, lt, ly), (ui, ut, uy))
+    assert hp["repeat_ratio"] == 1 and len(loaders["l"]) == 5 and len(loaders["u"]) == 4      # 9 / 2 (last chunk of 1 kept), 56 / 14
+    torch.manual_seed(0)
+    m = stil_tta_amd.create_model(hp)
+    if algo == "STiL":
+        m.setup_device("cuda")
+        m.prototypes.copy_(torch.nn.functional.normalize(torch.randn(3, 128, generator=torch.Generator().manual_seed(5))).cuda())
+    out = F.fit(m, loaders, _Val(vi, vt, vy, 16), max_epochs=2, eval_metric="acc", logdir=str(tmp_path), verbose=False, prefetch=False)
+    assert out["stopped"] == "max_epochs" and out["global_step"] == 2 * 5 and os.path.exists(out["checkpoint"])   # max_size_cycle: 5 steps per epoch
+    res = F.test(m, _Val(vi, vt, vy, 16), ckpt_path=out["checkpoint"])
+    assert abs(res["test.acc"] - out["best_score"]) < 1e-7
