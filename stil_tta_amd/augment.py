@@ -330,17 +330,28 @@ class IndexLoader:
     """torch DataLoader(dataset, batch_size, shuffle=True) over a device batch builder: one epoch = a fresh permutation of the
     builder's rows in chunks of `batch_size` (the last partial chunk is kept, like DataLoader's drop_last=False)."""
 
-    def __init__(self, builder, batch_size: int, shuffle: bool = True, seed: int = 2022, drop_last: bool = False):
+    def __init__(self, builder, batch_size: int, shuffle: bool = True, seed: int = 2022, drop_last: bool = False, rank: int = 0,
+                 world: int = 1):
+        """rank / world: the DistributedSampler Lightning installs under DDP -- every rank draws the SAME permutation (common
+        seed), pads it to a multiple of `world` by wrapping around and takes every world-th row starting at its rank."""
         self.builder, self.bs, self.shuffle, self.drop_last = builder, int(batch_size), bool(shuffle), bool(drop_last)
+        self.rank, self.world = int(rank), int(world)
         self.gen = torch.Generator().manual_seed(seed)
 
-    def __len__(self):
+    def _rows(self):
         n = len(self.builder)
+        return (n + self.world - 1) // self.world
+
+    def __len__(self):
+        n = self._rows()
         return n // self.bs if self.drop_last else (n + self.bs - 1) // self.bs
 
     def __iter__(self):
         n = len(self.builder)
         order = torch.randperm(n, generator=self.gen) if self.shuffle else torch.arange(n)
+        if self.world > 1:
+            total = self._rows() * self.world
+            order = torch.cat([order, order[: total - n]])[self.rank::self.world]
         for i in range(len(self)):
             yield self.builder(order[i * self.bs:(i + 1) * self.bs])
 
@@ -373,4 +384,6 @@ def semisl_loaders(hparams, labelled, unlabelled, device="cuda"):
     ratio = int(get("unlabelled_ratio", 7))
     put("repeat_ratio", repeat_ratio(len(unl), len(lab), ratio))
     l_bs, u_bs = split_batch_size(int(get("batch_size")), ratio)
-    return {"l": IndexLoader(lab, l_bs, seed=seed + 1), "u": IndexLoader(unl, u_bs, seed=seed + 2)}
+    import torch.distributed as dist
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+    return {"l": IndexLoader(lab, l_bs, seed=seed + 1, rank=rank, world=world), "u": IndexLoader(unl, u_bs, seed=seed + 2, rank=rank, world=world)}

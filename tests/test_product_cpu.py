@@ -372,3 +372,22 @@ def test_create_model_follows_the_references_algorithm_dispatch():
     assert "encoder_tabular.transformer.layers.0.0.fn.fn.to_qkv.weight" in S.create_model(dict(hp, algorithm_name="STiL_SAINT")).model.state_dict()
     with pytest.raises(ValueError):
         S.create_model(dict(hp, algorithm_name="FixMatch"))
+
+
+def test_index_loader_shuffles_and_shards_like_a_distributed_sampler():
+    from stil_tta_amd.augment import IndexLoader
+
+    class B:
+        def __len__(self):
+            return 11
+
+        def __call__(self, idx):
+            return idx.clone()
+
+    one = IndexLoader(B(), 4, seed=3)
+    e1, e2 = torch.cat(list(one)), torch.cat(list(one))
+    assert len(one) == 3 and sorted(e1.tolist()) == list(range(11)) and not torch.equal(e1, e2)      # reshuffled every epoch, partial chunk kept
+    parts = [torch.cat(list(IndexLoader(B(), 4, seed=3, rank=r, world=2))) for r in range(2)]
+    assert all(len(p) == 6 for p in parts) and set(parts[0].tolist()) | set(parts[1].tolist()) == set(range(11))
+    assert torch.equal(torch.stack(parts, 1).reshape(-1)[:11], e1)                               # the same permutation, dealt round-robin
+    assert len(IndexLoader(B(), 4, drop_last=True)) == 2 and torch.equal(torch.cat(list(IndexLoader(B(), 4, shuffle=False))), torch.arange(11))
