@@ -9,9 +9,15 @@ synthetic input already resident in HBM (224x224 images U
 continuous columns, K = 286, B_l = B/8, current_epoch > start_epoch so every loss term is live, MI-layer
 dropout active).  Weak scaling: every rank runs `--batch` (default 256, BASELINE.json configs[1]) samples.
 
+`--gpus N` with N > 1 and no torch.distributed.run environment (WORLD_SIZE unset) makes THIS process a launcher: before
+it touches the GPU it starts N fresh rank processes of this same script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+rendezvous on 127.0.0.1, one GPU each), forwards rank 0's line and exits with the first failing rank's code -- so
+`python bench.py --gpus 8` and the torch.distributed.run form above measure the same N-rank job (trainers/evaluate.py:170-179:
+the reference leaves the launch to Lightning's DDP strategy).
+
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the gemm_nt tile variant with the largest time share; fp32-exact MFMA
-implicit GEMM): algorithmic FLOPs of its launches / their HIP-event durations, both taken on the launch
-stream during the LAST timed step.  `cpu_baseline` is the oracle (a CPU port validated against the
+implicit GEMM): algorithmic FLOPs of its launches / their HIP-event durations, taken on the launch stream during
+extra steps that run AFTER the timed region (the timed steps carry no instrumentation).  `cpu_baseline` is the oracle (a CPU port validated against the
 reference) timed on this box's host cores on a bounded sample.
 """
 import argparse
@@ -58,7 +64,132 @@ def parse():
     ap.add_argument("--host-input", action="store_true", help="every step's batch starts in pageable host memory and goes through "
                     "data.DevicePrefetcher (PCIe-inclusive rate; NOT the contract's `value`, which has inputs resident in HBM)")
     ap.add_argument("--breakdown", action="store_true", help="also print per-entry-point GPU time of the last step (stderr)")
+    ap.add_argument("--cpu-b256", action="store_true", help="also time the CPU baseline at the bench's own batch 256 (BASELINE.md section 3; "
+                    "~2 min per step) and report it as cpu_baseline_b256")
+    ap.add_argument("--pipeline", choices=["resident", "device"], default="resident",
+                    help="device: additionally measure the device input pipeline (augment.ContrastiveBatchBuilder on a uint8 shard resident "
+                         "in HBM: crop / flip / jitter / gray / blur + tabular corruption) alone and inside the training loop; printed as a "
+                         "SEPARATE JSON line before the contract line, never `value`")
+    ap.add_argument("--launch-check", action="store_true", help="exercise only the N-rank launch, rendezvous, barrier and max-over-ranks "
+                    "timing protocol with an EMPTY step (no GPU, no model): the CPU test of the launcher; value is null")
     return ap.parse_args()
+
+
+def pipeline_measure(a, m, opt, dev, fl, train_step, rank, world):
+    """`--pipeline device`: SURVEY.md 8f rank 3 measured.  A uint8 HWC shard resident in HBM (what the reference's workers read
+    from `.npy`, datasets/ContrastiveImagingAndTabularDataset.py:177-198) goes through augment.ContrastiveBatchBuilder per step:
+    RandomResizedCrop / flip / ColorJitter / ToGray / GaussianBlur + the unaugmented view + marginal tabular corruption
+    (utils/utils.py:46-70 torchvision branch -- unpinned: neither torchvision nor albumentations exists offline; :146-158
+    `corrupt`, pinned bit for bit).  Returns the dict of the separate JSON line; never the contract's `value`."""
+    from stil_tta_amd.augment import ContrastiveBatchBuilder
+    N, P, B = 2048, a.img, a.batch
+    g = torch.Generator().manual_seed(99 + rank)
+    images = torch.randint(0, 256, (N, P, P, 3), dtype=torch.uint8, generator=g)
+    cat = [int(c) for c in fl if int(c) != 1]
+    table = torch.cat([torch.randint(0, c, (N, 1), generator=g).float() for c in cat] + [torch.randn(N, len(fl) - len(cat), generator=g)], dim=1)
+    labels = torch.randint(0, a.classes, (N,), generator=g)
+    target = "CAD" if a.variant == "cardiac" else "dvm"
+    lab = ContrastiveBatchBuilder(images, table, labels, P, target=target, labelled=True, device=dev, seed=2022 + 1000 * rank)
+    unl = ContrastiveBatchBuilder(images, table, labels, P, target=target, labelled=False, device=dev, seed=2122 + 1000 * rank)
+    Bl = max(B // 8, 1)
+
+    def build():
+        return {"l": lab(torch.randint(0, N, (Bl,), generator=g)), "u": unl(torch.randint(0, N, (B - Bl,), generator=g))}
+
+    for _ in range(2):
+        build()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        build()
+    torch.cuda.synchronize()
+    t_alone = (time.perf_counter() - t0) / a.steps
+    for _ in range(max(1, a.warmup)):
+        train_step(m, opt, build())
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        train_step(m, opt, build())
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t_loop = float(t.item()) / a.steps
+    # algorithmic bytes of one batch: the uint8 source rows are gathered (read + write), read by the blur / crop kernels and
+    # by the unaugmented resize; two float [B,3,P,P] outputs are written; the table is negligible
+    src_b, out_b = B * P * P * 3, B * 3 * P * P * 4
+    alg = 4 * src_b + 2 * out_b
+    return dict(metric="device input pipeline (ContrastiveBatchBuilder: crop/flip/jitter/gray/blur + tabular corruption), batches of the bench shape",
+                pipeline_ms_per_batch=round(t_alone * 1e3, 3), pipeline_samples_per_s=round(B / t_alone, 1),
+                algorithmic_bytes_per_batch=alg, hbm_gbps=round(alg / t_alone / 1e9, 1),
+                train_with_pipeline_samples_per_s=round(B * world / t_loop, 2), train_with_pipeline_ms_per_step=round(t_loop * 1e3, 3),
+                n_gpus=world, batch_per_gpu=B, shard=f"{N} uint8 {P}x{P}x3 images + {len(fl)} columns per rank, resident in HBM",
+                note="image transforms follow torchvision's branch of utils/utils.py and are UNPINNED (torchvision / albumentations / cv2 are "
+                     "absent offline); tabular corruption is pinned bit for bit (tests/golden/tab_corrupt.npz); this line is never `value`")
+
+
+def launch_ranks(a) -> int:
+    """`--gpus N` outside torch.distributed.run: N fresh rank processes, started BEFORE this process has made any GPU call
+    (a process that has initialised the GPU is never re-executed or forked).  Rank r gets LOCAL_RANK = r -> GPU r."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))   # rank 0 prints the line
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                c = p.poll()
+                if c is None:
+                    continue
+                pending.remove(p)
+                if c != 0 and rc == 0:
+                    rc = c
+                    for q in pending:      # one rank failed: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def launch_check(a):
+    """The bench protocol with an empty step: rendezvous (gloo), barrier, K timed no-op steps, barrier, MAX over ranks, rank 0
+    prints the line.  No GPU and no model: what it checks is that `--gpus N` really yields an N-rank job."""
+    from stil_tta_amd.driver import init_distributed
+    rank, world, local = init_distributed(backend="gloo")
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        pass
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps(dict(metric="training samples/sec (labeled+unlabeled) for DVM STiL", value=None, unit="samples/s", n_gpus=world,
+                              steps=a.steps, warmup=a.warmup, launch_check=True, local_ranks=sorted({local}),
+                              config=dict(global_batch=a.batch * world, parallelism=f"dp{world}"))), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def cpu_baseline(field_lengths, classes, img, batch, steps=3):
@@ -83,12 +214,18 @@ def cpu_baseline(field_lengths, classes, img, batch, steps=3):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))          # nothing below runs in the launcher; it has made no GPU call
+    if a.launch_check:
+        return launch_check(a)
     from stil_tta_amd import STiLModel
     from stil_tta_amd._lib import lib
     from stil_tta_amd.driver import init_distributed, train_step, synthetic_batch
     from stil_tta_amd.flat import StilAdam
 
     rank, world, local = init_distributed()
+    if world != a.gpus and rank == 0:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: following the launcher's environment", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path in the product)"
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
@@ -143,32 +280,34 @@ def main():
     t0 = time.perf_counter()
     L = lib()
     prof = prof_conc = None
-    for s in range(a.steps):
-        if feed:
-            batch = next(feed)
-        if s == a.steps - 1 and not a.graph:
-            # last timed step: HIP events around the GEMM launches only, on whichever stream they go to (both streams
-            # keep running: nothing about the step changes, the cost is two event records per launch)
-            L.begin_profile(single_stream=False, only=("gemm_nt",))
-        train_step(m, opt, batch)
+    for s in range(a.steps):      # the timed region carries no instrumentation
+        train_step(m, opt, next(feed) if feed else batch)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if L._prof is not None:
-        prof_conc = L.end_profile()
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    # OUTSIDE the timed region: one more step with every launch kept on ONE stream and bracketed by HIP events -- clean
-    # per-kernel durations (no second kernel sharing the chip), which is what the roofline of the kernel is priced on
+    # OUTSIDE the timed region, two more steps.  (1) the step as timed (both streams), HIP events around the GEMM launches on
+    # whichever stream they go to: the kernel while the side stream co-runs (`two_stream`).  (2) every launch kept on ONE
+    # stream and bracketed by HIP events: clean per-kernel durations (no second kernel sharing the chip), which is what
+    # the roofline of the kernel is priced on.
+    if not a.graph:
+        L.begin_profile(single_stream=False, only=("gemm_nt",))
+        train_step(m, opt, batch)
+        prof_conc = L.end_profile()
     L.begin_profile(only=None if a.breakdown else ("gemm_nt", "wgrad_tn"))
     (eager_step if a.graph else train_step)(m, opt, batch)
     torch.cuda.synchronize()
     prof = L.end_profile()
     loss = float(m.last["loss"].detach())
     assert loss == loss, "loss is NaN"
+    if a.pipeline == "device" and a.variant in ("dvm", "saint", "cardiac"):
+        pl = pipeline_measure(a, m, opt, dev, fl, eager_step if a.graph else train_step, rank, world)
+        if rank == 0:
+            print(json.dumps(pl), flush=True)
 
     if rank == 0:
         value = a.batch * world * a.steps / dt
@@ -191,23 +330,27 @@ def main():
                                  sorted(byvar.items(), key=lambda kv: -kv[1][1])},
                     note="achieved / avg_launch_us: HIP events around every launch of one extra step run right after the timed region "
                          "with all launches on ONE stream (agrees with profiles/*_single_stream.csv = this command with "
-                         "STIL_WGRAD_STREAM=0); two_stream: the same kernel during the LAST TIMED step, while the side stream (EMA "
+                         "STIL_WGRAD_STREAM=0); two_stream: the same kernel during another extra step, while the side stream (EMA "
                          "teacher, weight gradients) co-runs -- what a rocprofv3 trace of the default command averages "
                          "(profiles/*_bench_kernel_stats.csv)")
         # HBM traffic of that kernel: PMC counters cannot be read from inside the process; the latest separate-pass
-        # rocprofv3 measurement of this same command is kept under profiles/ and quoted when it is for this kernel.
+        # rocprofv3 measurement of this same command is kept under profiles/ and quoted ONLY while it is for this kernel AND was
+        # taken on these very kernel sources (kernel_source_sha = content hash of csrc/: the box has no .git to ask).
         try:
+            from stil_tta_amd._lib import source_hash
+            sha = source_hash()
             pdir = os.path.join(ROOT, "profiles")
             pmc = sorted(f for f in os.listdir(pdir) if f.endswith("pmc_traffic.json"))
             tj = json.load(open(os.path.join(pdir, pmc[-1]))) if pmc else None
-            if tj and tj["kernel"] == kname and a.batch == 256 and a.img == 224:
+            if tj and tj["kernel"] == kname and tj.get("kernel_source_sha") == sha and a.batch == 256 and a.img == 224:
                 roof["traffic"] = round(tj["bytes_per_launch"])
-                roof["traffic_source"] = "profiles/" + pmc[-1]
+                roof["traffic_source"] = f"profiles/{pmc[-1]} (kernel sources {sha})"
             mu = sorted(f for f in os.listdir(pdir) if f.endswith("mfma_util.json"))
             uj = json.load(open(os.path.join(pdir, mu[-1]))) if mu else None
-            if uj and kname in uj.get("kernels", {}) and a.batch == 256 and a.img == 224:
+            if uj and kname in uj.get("kernels", {}) and uj.get("kernel_source_sha") == sha and a.batch == 256 and a.img == 224:
                 roof["mfma_busy"] = uj["kernels"][kname]["mfma_busy_of_cu_busy"]
-                roof["mfma_busy_source"] = "profiles/" + mu[-1] + " (SQ_VALU_MFMA_BUSY_CYCLES / 4 / SQ_BUSY_CU_CYCLES, rocprofv3 --pmc on this command)"
+                roof["mfma_busy_source"] = (f"profiles/{mu[-1]} (kernel sources {sha}; SQ_VALU_MFMA_BUSY_CYCLES / 4 / SQ_BUSY_CU_CYCLES, "
+                                            "rocprofv3 --pmc on this command)")
         except Exception:
             pass
         if prof_conc:  # the same kernel while the second stream co-runs (what a rocprofv3 trace of this command averages)
@@ -252,6 +395,8 @@ def main():
                 print(f"    {str(k):44s} {v[0]:3d} {v[1]:8.3f} ms {v[2] / v[1] / 1e9:7.1f} TF", file=sys.stderr)
         if world == 1 and not a.no_cpu_baseline and a.variant == "dvm":
             out["cpu_baseline"] = cpu_baseline(fl, a.classes, a.img, a.cpu_batch, max(1, a.cpu_steps))
+            if a.cpu_b256 and a.cpu_batch != 256:
+                out["cpu_baseline_b256"] = cpu_baseline(fl, a.classes, a.img, 256, 1)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

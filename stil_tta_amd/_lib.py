@@ -46,6 +46,18 @@ def parse_header(path: str = HEADER):
     return protos
 
 
+def source_hash() -> str:
+    """Content hash of the kernel sources (csrc/*.hip, *.h): stamps profiler summaries under profiles/ with the build they
+    were taken on (the GPU box has no .git to ask), so that bench.py quotes them only while the kernels are unchanged."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
 def build(force: bool = False) -> str:
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]

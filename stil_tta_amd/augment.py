@@ -66,15 +66,15 @@ class TabularCorruptor:
         self.n_rows, self.n_cols = table.shape
         self.marginal = table.t().contiguous().to(device)   # generate_marginal_distributions: the table transposed
         self.k = int(self.n_cols * corruption_rate)
-        self.seed, self.calls = int(seed), 0
+        self.seed, self.drawn = int(seed), 0   # drawn: running total of counter values consumed (batches may differ in size)
 
     def draw(self, B: int):
         dev = self.marginal.device
         idx = torch.empty((B, max(self.k, 1)), dtype=torch.int32, device=dev)
         pos = torch.empty((B, max(self.k, 1)), dtype=torch.int32, device=dev)
         if self.k:
-            lib().tab_corrupt_draw(_p(idx), _p(pos), B, self.n_cols, self.n_rows, self.k, self.seed, self.calls * B * 2 * self.k, None, _stream())
-        self.calls += 1
+            lib().tab_corrupt_draw(_p(idx), _p(pos), B, self.n_cols, self.n_rows, self.k, self.seed, self.drawn, None, _stream())
+        self.drawn += B * 2 * self.k
         return idx, pos
 
     def __call__(self, clean: torch.Tensor, draws=None) -> torch.Tensor:
@@ -95,10 +95,15 @@ def resize_crop(src: torch.Tensor, boxes, P: int, flip=None, jitter=None) -> tor
     B = src.shape[0]
     H, W = (src.shape[1], src.shape[2]) if u8 else (src.shape[2], src.shape[3])
     scale = 1.0 / 255.0 if u8 else 1.0
+    if not (isinstance(boxes, torch.Tensor) and boxes.is_cuda):
+        # host-side boxes (the augmenter's numpy draws): checked here, before the upload, whatever the batch size -- no
+        # device round trip.  Boxes that already live on the device are clamped to the image inside the kernel instead.
+        b = np.asarray(boxes.cpu() if isinstance(boxes, torch.Tensor) else boxes).reshape(-1, 4)
+        if not bool(((b[:, 0] >= 0) & (b[:, 1] >= 0) & (b[:, 2] > 0) & (b[:, 3] > 0) & (b[:, 0] + b[:, 2] <= H) & (b[:, 1] + b[:, 3] <= W)).all()):
+            raise ValueError("crop box outside the source image")
     boxes = torch.as_tensor(boxes, dtype=torch.int32).to(dev).contiguous()
-    b = boxes.cpu() if boxes.is_cuda and boxes.numel() <= 4096 else None
-    if b is not None and not bool(((b[:, 0] >= 0) & (b[:, 1] >= 0) & (b[:, 2] > 0) & (b[:, 3] > 0) & (b[:, 0] + b[:, 2] <= H) & (b[:, 1] + b[:, 3] <= W)).all()):
-        raise ValueError("crop box outside the source image")   # the kernel trusts the boxes: check them on the host
+    if boxes.shape != (B, 4):
+        raise ValueError(f"boxes must be [B, 4] = {(B, 4)}, got {tuple(boxes.shape)}")
     flip = None if flip is None else torch.as_tensor(flip).to(dev, torch.uint8).contiguous()
     gmean = None
     if jitter is not None:
@@ -371,6 +376,10 @@ def semisl_loaders(hparams, labelled, unlabelled, device="cuda"):
             setattr(hparams, k, v)
 
     algo, seed = get("algorithm_name", "STiL"), int(get("seed", 2022))
+    import torch.distributed as dist
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+    sampler_seed = seed           # the sampler permutation is COMMON to the ranks (DistributedSampler); the augmentation / corruption
+    seed = seed + 1000 * rank     # draws are per rank (Lightning's seed_everything(workers=True) seeds workers by global rank)
     common = dict(img_size=get("img_size"), target=get("target", "dvm"), corruption_rate=get("corruption_rate", 0.3), device=device)
     (il, tl, yl), (iu, tu, yu) = labelled, unlabelled
     if algo in ("CoMatch", "SimMatch", "FreeMatch"):
@@ -384,6 +393,5 @@ def semisl_loaders(hparams, labelled, unlabelled, device="cuda"):
     ratio = int(get("unlabelled_ratio", 7))
     put("repeat_ratio", repeat_ratio(len(unl), len(lab), ratio))
     l_bs, u_bs = split_batch_size(int(get("batch_size")), ratio)
-    import torch.distributed as dist
-    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
-    return {"l": IndexLoader(lab, l_bs, seed=seed + 1, rank=rank, world=world), "u": IndexLoader(unl, u_bs, seed=seed + 2, rank=rank, world=world)}
+    return {"l": IndexLoader(lab, l_bs, seed=sampler_seed + 1, rank=rank, world=world),
+            "u": IndexLoader(unl, u_bs, seed=sampler_seed + 2, rank=rank, world=world)}

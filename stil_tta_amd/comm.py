@@ -32,10 +32,16 @@ class GradExchange:
 
     Buckets are contiguous slab ranges of ~`bucket_elems` floats cut at tensor boundaries.  How many "+=" each parameter
     receives in one backward pass (shared weights receive several) is LEARNED: the first step under a given signature
-    (the model's set of live loss terms) runs with a plain post-backward exchange and records the per-tensor touch
-    counts and the order in which buckets completed; later steps launch each bucket as soon as its counts are met,
-    always in that recorded order (every rank issues the same sequence of collectives whatever its autograd engine
-    does).  A gradient arriving for a bucket that has already left is a bug and raises."""
+    (the model's set of live loss terms) runs with a plain post-backward exchange of EVERY bucket in index order and
+    records the per-tensor touch counts and the order in which buckets completed.  The plan is then AGREED between the
+    ranks: rank 0's counts and order are broadcast, every rank compares its own counts with them, and only if all ranks
+    agree (one MIN all-reduce) does the signature enter overlap mode -- with rank 0's order on every rank; otherwise the
+    signature stays on the post-backward exchange for good.  Later steps launch each bucket as soon as its counts are
+    met, always in the agreed order, so every rank issues the same sequence of collectives whatever its autograd engine
+    does.  Every step additionally opens with one 4-word MAX all-reduce of (signature hash, mode): ranks that disagree on
+    either would issue different collective sequences, and all of them raise instead of hanging in RCCL.  A gradient
+    arriving for a bucket that has already left, or a changed set of touched parameters, raises -- but only after this
+    rank has issued the step's full collective sequence, so the other ranks are never left blocked."""
 
     def __init__(self, flat, bucket_elems: int = 8 << 20):
         self.flat = flat
@@ -54,9 +60,11 @@ class GradExchange:
             self.bucket_of.append(len(self.ranges))
         self.ranges.append((start, ends[-1]))
         self.tid = {id(t): i for i, t in enumerate(flat.tensors)}
-        self.plans: Dict[object, Tuple[List[int], List[int]]] = {}   # signature -> (expected touches per tensor, bucket order)
+        # signature -> (expected touches per tensor, bucket order) once agreed, or None = "the ranks disagreed: never overlap"
+        self.plans: Dict[object, Optional[Tuple[List[int], List[int]]]] = {}
         self.comm_stream: Optional[torch.cuda.Stream] = None
         self.active = False
+        self._check = None            # (work, tensor, what) of the step-opening agreement all-reduce, verified lazily
         self._reset(None)
 
     def _reset(self, sig):
@@ -69,6 +77,7 @@ class GradExchange:
         self.works = []
         self.fired = set()
         self.ready = set()
+        self.bad = None               # first protocol violation of this step (raised at the end of finish())
         plan = self.plans.get(sig) if (sig is not None and self.enabled and self.active) else None
         self.expect, self.fire_order = plan if plan else (None, None)
         self.next_fire = 0
@@ -77,10 +86,72 @@ class GradExchange:
             for i, c in enumerate(self.expect):
                 self.remaining[self.bucket_of[i]] += c
 
+    # ---- agreement between the ranks
+    def _comm(self, fn, t):
+        """Run collective `fn(t)` on the communication stream (device tensors) or inline (host tensors); returns the work."""
+        if t.is_cuda:
+            if self.comm_stream is None:
+                self.comm_stream = torch.cuda.Stream(t.device)
+            with torch.cuda.stream(self.comm_stream):
+                return fn(t)
+        return fn(t)
+
+    @staticmethod
+    def _capturing() -> bool:
+        return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+    def _open_check(self):
+        """Every rank must be at the same signature and in the same mode (learning / post-backward vs overlap)."""
+        import zlib
+        h = zlib.crc32(repr(self.sig).encode()) & 0x7fffffff
+        mode = 0 if self.expect is None else 1
+        t = torch.tensor([h, -h, mode, -mode], dtype=torch.int64, device=self.flat._grads.device)
+        wk = self._comm(lambda x: dist.all_reduce(x, op=dist.ReduceOp.MAX, async_op=True), t)
+        self._check = (wk, t, f"signature {self.sig!r}, mode {'overlap' if mode else 'post-backward'}")
+
+    def verify(self):
+        """Host check of the last step-opening agreement (reads 4 words; the collective was the first one of its step)."""
+        if self._check is None:
+            return
+        wk, t, what = self._check
+        self._check = None
+        wk.wait()
+        v = t.tolist()
+        if v[0] != -v[1] or v[2] != -v[3]:
+            raise RuntimeError(f"data-parallel ranks disagree on the gradient exchange of this step (this rank: {what}; "
+                               f"hash max/min {v[0]}/{-v[1]}, mode max/min {v[2]}/{-v[3]}): refusing to issue mismatched collectives")
+
+    def _agree_plan(self, counts, order):
+        """Rank 0's (counts, order) become the plan iff every rank counted the same touches; else None (never overlap)."""
+        nb = len(self.ranges)
+        mine = torch.tensor(list(counts) + list(order) + [-1] * (nb - len(order)), dtype=torch.int64, device=self.flat._grads.device)
+        plan = mine.clone()
+        self._comm(lambda x: dist.broadcast(x, src=0), plan)
+        if plan.is_cuda:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        n = len(counts)
+        same = bool((plan[:n] == mine[:n]).all().item())
+        ok = torch.tensor([1 if same else 0], dtype=torch.int64, device=mine.device)
+        self._comm(lambda x: dist.all_reduce(x, op=dist.ReduceOp.MIN), ok)
+        if ok.is_cuda:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if int(ok.item()) != 1:
+            import warnings
+            warnings.warn(f"GradExchange: the ranks' backward passes touch different parameters under signature {self.sig!r}; "
+                          "this signature keeps the post-backward exchange (no overlap)")
+            return None
+        pl = plan.tolist()
+        return pl[:n], [b for b in pl[n:] if b >= 0]
+
     # ---- called by the step driver
     def begin(self, sig):
         """Start of backward.  `sig` identifies the set of live loss terms (None: never overlap)."""
+        capturing = self._capturing()
+        if not capturing:
+            self.verify()             # the previous step's agreement (long complete: no stall)
         self._reset(sig)
+        if self.active and not capturing:
+            self._open_check()
 
     def note(self, param):
         """One gradient contribution to `param` has been ISSUED (on the current or the side stream)."""
@@ -96,8 +167,9 @@ class GradExchange:
         if self.expect is None:            # learning step / no overlap: everything leaves in finish()
             return
         if b in self.fired:
-            raise RuntimeError(f"gradient for {self.flat.names[i]} arrived after its bucket was all-reduced "
-                               "(the backward graph changed under an unchanged signature)")
+            self.bad = self.bad or (f"gradient for {self.flat.names[i]} arrived after its bucket was all-reduced "
+                                    "(the backward graph changed under an unchanged signature)")
+            return
         self.remaining[b] -= 1
         if self.remaining[b] == 0:
             self.ready.add(b)
@@ -128,16 +200,20 @@ class GradExchange:
         if not self.active:
             return 1.0
         self.flat.grads  # joins the side stream (weight gradients) into the current one
+        learned = None
         if self.expect is None:
-            # buckets that received gradients, ordered by their LAST contribution (the order they can leave in next time)
-            order = sorted(self.last_touch, key=self.last_touch.get)
-            if self.sig is not None and self.enabled:
-                self.plans[self.sig] = (list(self.counts), order)
-            pending = order
+            # post-backward exchange: EVERY bucket, in index order -- the same sequence on every rank whatever its
+            # autograd engine did.  First make sure all ranks are here in this mode (a rare step: the host read is free).
+            if not self._capturing():
+                self.verify()
+            pending = list(range(len(self.ranges)))
+            if self.sig is not None and self.enabled and self.sig not in self.plans:
+                # buckets that received gradients, ordered by their LAST contribution (the order they can leave in next time)
+                learned = (list(self.counts), sorted(self.last_touch, key=self.last_touch.get))
         else:
             if self.counts != self.expect:
-                raise RuntimeError("the set of parameters receiving gradients changed under an unchanged signature")
-            pending = self.fire_order[self.next_fire:]
+                self.bad = self.bad or "the set of parameters receiving gradients changed under an unchanged signature"
+            pending = list(self.fire_order[self.next_fire:])   # the agreed plan covers exactly the buckets every rank touches
         for b in pending:
             if b not in self.fired:
                 self._fire(b)
@@ -145,6 +221,10 @@ class GradExchange:
             wk.wait()
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if learned is not None:
+            self.plans[self.sig] = self._agree_plan(*learned)
+        if self.bad:
+            raise RuntimeError(self.bad)
         return 1.0 / world_size()
 
 

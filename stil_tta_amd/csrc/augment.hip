@@ -83,7 +83,9 @@ __device__ __forceinline__ void aug_fetch(const AugArgs& p, int b, int y, int x,
 }
 
 __device__ __forceinline__ void aug_sample(const AugArgs& p, int b, int oy, int ox, float (&rgb)[3]) {
-  const int top = p.box[b * 4 + 0], left = p.box[b * 4 + 1], ch = p.box[b * 4 + 2], cw = p.box[b * 4 + 3];
+  // the box is clamped to the image: a bad caller-supplied box can change the picture, never read outside it
+  const int top = min(max(p.box[b * 4 + 0], 0), p.H - 1), left = min(max(p.box[b * 4 + 1], 0), p.W - 1);
+  const int ch = min(max(p.box[b * 4 + 2], 1), p.H - top), cw = min(max(p.box[b * 4 + 3], 1), p.W - left);
   if (p.flip && p.flip[b]) ox = p.P - 1 - ox;   // flipping the output == flipping the crop before the resize
   const float sy = (float)ch / (float)p.P, sx = (float)cw / (float)p.P;
   float fy = ((float)oy + 0.5f) * sy - 0.5f, fx = ((float)ox + 0.5f) * sx - 0.5f;

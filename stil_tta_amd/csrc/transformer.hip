@@ -414,9 +414,10 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs p) {
   const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
   const int d = p.d, d4 = d >> 2, Sq = p.Sq, Skv = p.Skv, SqP = attn_up16(Sq), SkP = attn_up16(Skv);
   const int dq = d + 4, dp = attn_pad(d), dt = attn_padT(d), sp = attn_pad(SkP);
-  float* R0 = sh;                  // dO as [SqP][dp], later Q as [SqP][dt]
-  float* R1 = R0 + SqP * dp;       // V as [SkP][dq], later K as [SkP][dt]
-  float* X = R1 + SkP * dt;        // [SqP][sp]: dropped probabilities Pd, later dP -> dS (time-shared: one tile matrix, not two)
+  // Each region is sized by its LARGER occupant (dt > dp for d = 32, 48, 96, 112; dq > dt for d = 16, 80, 144): attn_mfma_lds
+  float* R0 = sh;                                // dO as [SqP][dp], later Q as [SqP][dt]
+  float* R1 = R0 + SqP * (dp > dt ? dp : dt);    // V as [SkP][dq], later K as [SkP][dt]
+  float* X = R1 + SkP * (dq > dt ? dq : dt);     // [SqP][sp]: dropped probabilities Pd, later dP -> dS (time-shared: one tile matrix, not two)
   const long ld = 3L * p.H * d;
   const float* base = p.qkv + (long)b * p.T * ld + h * d;
   float* dbase = p.dqkv + (long)b * p.T * ld + h * d;
@@ -727,7 +728,8 @@ static int attn_check(int T, int H, int d, int q_off, int Sq, int kv_off, int Sk
 // LDS of the MFMA kernels (padded tiles) and their eligibility: head dim a multiple of 16, everything in 160 KiB
 static size_t attn_mfma_lds(int Sq, int Skv, int d, bool bwd) {
   const int SqP = attn_up16(Sq), SkP = attn_up16(Skv), dp = attn_pad(d), sp = attn_pad(SkP);
-  const size_t fl = bwd ? (size_t)SqP * dp + (size_t)SkP * attn_padT(d) + (size_t)SqP * sp     // dO/Q, V/K, Pd -> dP -> dS
+  const int dt = attn_padT(d), dq = d + 4;
+  const size_t fl = bwd ? (size_t)SqP * (dp > dt ? dp : dt) + (size_t)SkP * (dq > dt ? dq : dt) + (size_t)SqP * sp     // dO/Q, V/K, Pd -> dP -> dS
                         : (size_t)SqP * (d + 4) + (size_t)SkP * dp + (size_t)SqP * sp;        // Q, K/V, P
   return fl * sizeof(float);
 }

@@ -128,6 +128,11 @@ def load_adam_state_dict(model, optimizer, sd: dict) -> None:
     flat.exp_avg_sq.zero_()
     for pid, st in sd["state"].items():
         p = order[int(pid)]
+        if id(p) not in off:
+            # a frozen copy inside the group (the baselines' momentum encoders): torch's Adam never creates state for a
+            # parameter without gradient, so an entry here means the checkpoint belongs to another parameter list
+            raise KeyError(f"optimizer state entry {pid} refers to a parameter outside the gradient slab (a frozen copy): "
+                           "this checkpoint was not written for this model's optimizer groups")
         o = (p.data_ptr() - flat.params.data_ptr()) // 4
         n = p.numel()
         flat.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))

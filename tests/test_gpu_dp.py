@@ -211,3 +211,23 @@ def test_rccl_collectives_accept_the_slab_views():
             raise AssertionError("the RCCL worker hung and was killed: investigate from its output")
         assert p.exitcode == 0
         assert open(os.path.join(td, "ok")).read() == "1"
+
+
+def test_bench_gpus_2_runs_two_ranks_end_to_end():
+    """`python bench.py --gpus 2` as the driver calls it (no torch.distributed.run environment): the launcher starts two fresh
+    ranks before touching the GPU, both run the real step (gloo here: they share the box's one GPU, which RCCL refuses), the
+    gradient exchange agrees its bucket plan between the ranks, rank 0 prints ONE line with n_gpus 2 / dp2 and a whole-job value."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["STIL_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "16", "--img", "64", "--ncat", "3", "--ncon", "5",
+           "--classes", "7", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = lines[0]
+    assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "dp2" and j["config"]["global_batch"] == 32 and j["scaling"] == "weak"
+    assert j["value"] > 0 and abs(j["value"] - 32 * 1e3 / j["ms_per_step"]) < 1e-2 * j["value"]   # whole-job samples / max-over-ranks time
+    assert j["roofline"]["frac"] > 0 and "cpu_baseline" not in j

@@ -216,7 +216,12 @@ def _ref_attn(qkv, H, win, mask, p):
     (2, 12, 4, 128, [(1, 4, 1, 4), (5, 7, 5, 7), (0, 1, 0, 12)], True), (2, 114, 4, 128, [(1, 49, 1, 49), (50, 64, 50, 64), (0, 1, 0, 114)], True),
     (2, 9, 4, 16, [(0, 9, 0, 9)], False),
     (2, 10, 2, 12, [(0, 10, 0, 10)], True),          # head dim not a multiple of 16: the VALU kernels
-    (2, 96, 2, 64, [(0, 96, 0, 96)], True)])         # a 6 x 6 tile grid of the MFMA kernels
+    (2, 96, 2, 64, [(0, 96, 0, 96)], True),          # a 6 x 6 tile grid of the MFMA kernels
+    # MFMA backward with head dims whose LDS regions are sized by the SECOND occupant (round-2 advisor finding: V with stride
+    # d + 4 > padT(d) for d = 16, 80; Q with stride padT(d) > pad(d) for d = 32, 48, 96): SAINT's column attention is (65, 8, 16)
+    (2, 65, 8, 16, [(0, 65, 0, 65)], False), (2, 65, 8, 16, [(0, 65, 0, 65)], True), (2, 70, 4, 32, [(0, 70, 0, 70)], True),
+    (2, 80, 2, 48, [(0, 80, 0, 80)], False), (2, 50, 2, 80, [(0, 50, 0, 50)], True), (2, 64, 2, 96, [(0, 64, 0, 64)], True),
+    (2, 114, 4, 32, [(1, 49, 1, 49), (50, 64, 50, 64), (0, 1, 0, 114)], True)])
 def test_attention(ops, B, T, H, d, wins, use_mask):
     """softmax(q k^T) (dropout) v, forward and backward (models/Transformer.py:63-88, disentangle_transformer.py:49-94).
     Head dims that are multiples of 16 run on the matrix pipe (attn_*_mfma_kernel, v_mfma_f32_16x16x4_f32)."""

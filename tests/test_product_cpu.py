@@ -4,6 +4,7 @@ gloo (world_size 2), and the "no silent fallback" rule."""
 import ctypes
 import os
 import sys
+import time
 
 import pytest
 import torch
@@ -179,39 +180,77 @@ def _exchange_worker(rank, world, port, q):
     ex = GradExchange(flat, bucket_elems=4096)
     nb = len(ex.ranges)
     ok = nb >= 3 and ex.bucket_of[3] != ex.bucket_of[4]      # the gap cuts a bucket
-    touch_plan = [5, 4, 4, 3, 2, 1, 0]                        # p4 is a shared weight: two contributions per backward
-    fired_early = []
+    # p4 is a shared weight: two contributions per backward.  The two ranks' autograd engines deliver in DIFFERENT orders:
+    # every rank must adopt rank 0's bucket order (round-2 advisor finding: a per-rank plan is a silent RCCL deadlock)
+    touch_plan = [5, 4, 4, 3, 2, 1, 0] if rank == 0 else [0, 1, 4, 2, 3, 4, 5]
+    fired_early, fired_before_finish = [], []
     for step in range(3):
         flat._grads.zero_()
         ex.begin(("sig",))
         for k, i in enumerate(touch_plan):
             flat.tensors[i]._gslot.add_(float(rank + 1) * (i + 1))
             ex.note(flat.tensors[i])
-            if k == 3:
+            if k == 5:
                 fired_early.append(len(ex.fired))
+        fired_before_finish.append(len(ex.fired))
         scale = ex.finish()
         want = torch.zeros_like(flat._grads)
         for i in touch_plan:
             o = flat.tensors[i]._gslot.data_ptr() - flat._grads.data_ptr()
             want[o // 4: o // 4 + flat.tensors[i].numel()] += (i + 1) * sum(range(1, world + 1))
         ok = ok and scale == 1.0 / world and bool(torch.equal(flat._grads, want))
-    ok = ok and fired_early[0] == 0 and fired_early[1] >= 1 and fired_early[2] >= 1   # step 0 learns, later steps overlap
-    # a contribution arriving after its bucket has left must fail loudly
+    # step 0 learns, later steps overlap: in rank 0's order [3, 2, 1, 0] (rank 1 completes bucket 3 last and holds the others back)
+    ok = ok and fired_early[0] == 0 and fired_before_finish == [0, nb, nb]
+    ok = ok and (fired_early[1:] == [3, 3] if rank == 0 else fired_early[1:] == [0, 0])
+    agreed = ex.plans[("sig",)]
+    orders = [None] * world
+    dist.all_gather_object(orders, (agreed[0], agreed[1]))
+    ok = ok and all(o == orders[0] for o in orders)            # ONE plan: rank 0's counts and order on every rank
+    # a contribution arriving after its bucket has left must fail loudly -- after this rank has issued the whole sequence
     ex.begin(("sig",))
     raised = False
+    for i in touch_plan + [5 if rank == 0 else 0]:
+        ex.note(flat.tensors[i])
     try:
-        for i in touch_plan + [5]:
-            ex.note(flat.tensors[i])
-    except RuntimeError:
-        raised = True
-    for wk in ex.works:
-        wk.wait()
+        ex.finish()
+    except RuntimeError as e:
+        raised = "arrived after its bucket" in str(e)
     ok = ok and raised
     # a new signature learns again (no overlap on its first step)
     ex.begin(("other",))
     ex.note(flat.tensors[0])
     ok = ok and len(ex.fired) == 0
     ex.finish()
+    ok = ok and ex.plans[("other",)] is not None
+    # ranks whose backward passes touch DIFFERENT parameters never enter overlap mode under that signature (and still sum)
+    import warnings
+    for step in range(2):
+        flat._grads.zero_()
+        ex.begin(("ragged",))
+        for i in ([0, 1] if rank == 0 else [0, 2]):
+            flat.tensors[i]._gslot.add_(1.0)
+            ex.note(flat.tensors[i])
+        ok = ok and len(ex.fired) == 0
+        with warnings.catch_warnings(record=True) as wlist:
+            warnings.simplefilter("always")
+            ex.finish()
+        ok = ok and (len(wlist) == 1) == (step == 0)
+        ok = ok and float(flat.tensors[0]._gslot[0]) == 2.0 and float(flat.tensors[1]._gslot[0]) == 1.0 and float(flat.tensors[2]._gslot[0]) == 1.0
+    ok = ok and ex.plans[("ragged",)] is None
+    # ranks at different signatures (one would learn while the other overlaps): every rank raises before any bucket leaves
+    ex.begin(("left",) if rank == 0 else ("right",))
+    raised = False
+    try:
+        ex.finish()
+    except RuntimeError as e:
+        raised = "disagree" in str(e)
+    ok = ok and raised and len(ex.fired) == 0
+    ex.begin(("sig",) if rank == 0 else ("fresh",))           # modes differ too (overlap vs learning); caught at the next begin / finish
+    try:
+        ex.verify()
+        ok = False
+    except RuntimeError as e:
+        ok = ok and "disagree" in str(e)
     # autograd-aware all-gather: every rank evaluates the same global loss; backward = SUM all-reduce, own rows
     x = (torch.arange(6, dtype=torch.float32).reshape(3, 2) + 10 * rank).requires_grad_()
     g = AllGatherFn.apply(x)
@@ -239,6 +278,41 @@ def test_overlapped_gradient_exchange_and_autograd_collectives_world2_gloo():
     weights, late contributions refused), comm.AllGatherFn and the one-message buffer broadcast, two gloo ranks."""
     res = _run_ranks(_exchange_worker)
     assert res == {0: True, 1: True}
+
+
+# ---------------------------------------------------------------- bench.py --gpus N is an N-rank job (SURVEY.md 8d / 8e)
+def _bench_lines(cmd, extra_env=None, timeout=240):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env or {})
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    return r.returncode, [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")], r.stderr
+
+
+def test_bench_gpus_flag_launches_n_ranks():
+    """`python bench.py --gpus 2` (the driver's form for N = 1, round-2 verdict: the flag was dead) must run TWO ranks and
+    print ONE line with n_gpus 2 / dp2; under torch.distributed.run (the driver's form for N > 1) it must NOT launch again."""
+    rc, lines, err = _bench_lines([sys.executable, "bench.py", "--gpus", "2", "--launch-check", "--steps", "2"])
+    assert rc == 0, err
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["config"]["parallelism"] == "dp2" and lines[0]["config"]["global_batch"] == 512
+    rc, lines, err = _bench_lines([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                   "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--launch-check", "--steps", "2"])
+    assert rc == 0, err
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["config"]["parallelism"] == "dp2"
+    rc, lines, err = _bench_lines([sys.executable, "bench.py", "--launch-check"])
+    assert rc == 0 and len(lines) == 1 and lines[0]["n_gpus"] == 1
+
+
+def test_bench_launcher_propagates_a_failing_rank():
+    """The real bench needs a GPU: on this CPU box every rank fails its assert; the launcher must return non-zero, print no
+    line and leave no rank behind (the surviving ranks would otherwise wait in the rendezvous forever)."""
+    t0 = time.time()
+    rc, lines, err = _bench_lines([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                                  extra_env={"STIL_DIST_BACKEND": "gloo"})
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the ranks do not fail here (tests/test_gpu_dp.py runs the real two-rank bench)")
+    assert rc != 0 and lines == [] and "needs a GPU" in err and time.time() - t0 < 200
 
 
 # ---------------------------------------------------------------- fit-loop host logic (stil_tta_amd/fit.py)

@@ -10,6 +10,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from stil_tta_amd._lib import source_hash  # noqa: E402
+
 pmc_dir, out, cmd = sys.argv[1:4]
 agg = {}
 for f in glob.glob(os.path.join(pmc_dir, "**", "*counter_collection.csv"), recursive=True):
@@ -30,7 +33,7 @@ for k, a in agg.items():
     res[k] = dict(launches=n, mfma_busy_of_cu_busy=round(mf / 4.0 / cu, 4) if cu else None,
                   mfma_busy_of_gpu_time=round((mf / 1024.0) / (gui / 8.0), 4) if gui else None,
                   SQ_VALU_MFMA_BUSY_CYCLES=mf, SQ_BUSY_CU_CYCLES=cu, GRBM_GUI_ACTIVE=gui)
-json.dump({"method": f"rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -- `{cmd}` (counters only, no trace domains); "
+json.dump({"kernel_source_sha": source_hash(), "method": f"rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -- `{cmd}` (counters only, no trace domains); "
                      "sums over every launch of the kernel", "kernels": dict(sorted(res.items(), key=lambda kv: -kv[1]["SQ_VALU_MFMA_BUSY_CYCLES"]))},
           open(out, "w"), indent=1)
 print(open(out).read()[:3000])

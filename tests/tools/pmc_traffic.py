@@ -9,6 +9,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from stil_tta_amd._lib import source_hash  # noqa: E402
+
 
 def fold(d, counter):
     agg = {}
@@ -39,7 +42,7 @@ with open(prefix + "_pmc_traffic_by_kernel.csv", "w") as f:
 hit = [r for r in rows if r[0].replace("void ", "").startswith(kernel)]
 assert hit, f"{kernel} not in the trace"
 k, n, rb, wb, _ = hit[0]
-json.dump({"kernel": kernel, "launches": n, "read_bytes_per_launch": rb, "write_bytes_per_launch": wb, "bytes_per_launch": rb + wb,
+json.dump({"kernel": kernel, "kernel_source_sha": source_hash(), "launches": n, "read_bytes_per_launch": rb, "write_bytes_per_launch": wb, "bytes_per_launch": rb + wb,
            "method": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in two separate passes of `{cmd}`; bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 "
                      "(gfx950: FETCH_SIZE reports half of a wide coalesced read, MI355X_MICROARCH.md HBM section), averaged over the kernel's launches",
            "all_kernels_total_bytes": total}, open(prefix + "_pmc_traffic.json", "w"), indent=1)
