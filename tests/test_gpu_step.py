@@ -375,6 +375,80 @@ def test_baseline_shape_step_matches_oracle():
     assert not bad, f"{len(bad)} mismatches, first: {bad[:10]}"
 
 
+def test_configs1_full_size_forward_matches_oracle():
+    """BASELINE.json configs[1] at FULL size -- ResNet-50, 224 px, 16 categorical + 48 continuous columns, K = 286, B = 256
+    (32 labelled + 224 unlabelled), pseudo-label phase, injected mask_random and MI-layer dropout masks: every forward
+    quantity of STiLModel.training_step (:228-345: logits, features, teacher outputs, CGPL / PGLS pseudo-labels, all 11 loss
+    terms, class sums) through the HIP path against oracle.training_step on the host cores (no_grad: two oracle passes,
+    the first one also crafts the heads), and EXACT CGPL case ids / mask1.  Backward at this size is covered by the B = 32
+    oracle test above and the B = 256 properties below."""
+    from oracle.make_golden import randomize_state, make_mi_masks
+    fl = [8] * 16 + [1] * 48
+    B, K = 256, 286
+    hp = O.default_hparams(img_size=224, field_lengths=fl, num_classes=K, batch_size=B, start_epoch=0, th1=0.5)
+    sd = randomize_state(O.init_state(hp, seed=31), seed=32)
+    g = torch.Generator().manual_seed(33)
+    sd["prototypes"] = torch.nn.functional.normalize(torch.randn(K, hp.projection_dim, generator=g))
+    batch = O.synthetic_batch(hp, B, seed=2022)
+    B_u = len(batch["u"][2])
+    mr = torch.rand(B_u, generator=g).ge(0.5)
+    mm = {0: make_mi_masks(B, 49, len(fl), 512, 4, hp.mi_drop, seed=6)}
+    # the head coupling / centring of oracle.make_golden.craft_heads (mixed CGPL cases), with its oracle pass shared:
+    C = hp.multimodal_embedding_dim
+    scale = 6.0
+    for pre_ in ("model.", "ema."):
+        sd[pre_ + "classifier_multimodal.weight"][:, 512:1024] *= 0.3
+        sd[pre_ + "classifier_multimodal.weight"][:, 1024:] *= 28.0
+        Wm = sd[pre_ + "classifier_multimodal.weight"]
+        sd[pre_ + "classifier_imaging.weight"][:, :C] = Wm[:, :C]
+        sd[pre_ + "classifier_tabular.weight"][:, :C] = Wm[:, 2 * C:]
+        sd[pre_ + "classifier_imaging.weight"][:, C:] *= 0.2
+        sd[pre_ + "classifier_tabular.weight"][:, C:] *= 0.2
+    with torch.no_grad():
+        o1 = O.training_step({k: v.clone() for k, v in sd.items()}, batch, hp, 1, mr, mm)
+    for nm, key in (("classifier_multimodal", "y_hat_m_e"), ("classifier_imaging", "y_hat_i_e"), ("classifier_tabular", "y_hat_t_e")):
+        mean = o1[key].mean(0)
+        for pre_ in ("model.", "ema."):
+            sd[pre_ + nm + ".weight"] *= scale
+            sd[pre_ + nm + ".bias"] = (sd[pre_ + nm + ".bias"] - mean) * scale
+    # th1 in the widest gap of the confidence ranking.  Under the crafted heads the teacher's multimodal logits are
+    # (y_hat_m_e - mean) * scale and the prototype similarities are unchanged, so `prediction` follows from pass 1
+    # (STiLModel.py:276-296); the second oracle pass below re-derives it and is what the device is compared with.
+    zm = (o1["y_hat_m_e"] - o1["y_hat_m_e"].mean(0)) * scale
+    tp = torch.softmax(o1["feat_m_e"][B - B_u:] @ sd["prototypes"].t() / hp.temperature, dim=1)
+    pred = hp.rate_pseudo * torch.softmax(zm[B - B_u:], dim=1) + (1 - hp.rate_pseudo) * tp
+    conf = pred.max(1)[0].sort()[0]
+    lo = B_u // 4
+    gaps = conf[lo + 1: B_u - lo + 1] - conf[lo: B_u - lo]
+    j = int(gaps.argmax()) + lo
+    hp.th1 = float((conf[j] + conf[j + 1]) / 2)
+    assert float(gaps.max()) > 2e-4, "no rounding-proof th1 on this batch"
+    sd0 = {k: v.clone() for k, v in sd.items()}
+    with torch.no_grad():
+        o = O.training_step(sd, batch, hp, 1, mr, mm)
+    assert float((o["prediction"] - pred).abs().max()) < 1e-3
+    assert 0 < int(o["mask1"].sum()) < B_u
+    assert sum(int(o[c].sum()) > 0 for c in ("case1", "case2_i", "case2_t", "case3")) >= 3, "CGPL cases must be mixed"
+
+    m = _make_model(hp, sd0)
+    m.current_epoch = 1
+    with torch.no_grad():
+        m.training_step(_to_dev(batch), 0, mask_random=mr, mi_masks=mm)
+    torch.cuda.synchronize()
+    bad, beyond = [], []
+    for k in SCALARS + FWD_KEYS:
+        d = _scaled(m.last[k].detach().cpu().numpy(), o[k].numpy())
+        _worst["scaled"] = max(_worst.get("scaled", 0.0), d)
+        if d > TOL:
+            beyond.append((k, f"{d:.2e}"))
+        if d > NORTH_STAR:
+            bad.append((k, d))
+    _check_flags(m.last, o, B_u)
+    print(f"configs[1] full size: th1 = {hp.th1:.4f}, mask1 {int(o['mask1'].sum())}/{B_u}, cases "
+          f"{[int(o[c].sum()) for c in ('case1', 'case2_i', 'case2_t', 'case3')]}; beyond {TOL:g} (bar {NORTH_STAR:g}): {beyond}")
+    assert not bad, f"{len(bad)} forward quantities beyond the north-star 1e-4: {bad[:10]}"
+
+
 @pytest.mark.parametrize("B", [32, 256])
 def test_bench_shape_properties(B):
     """BASELINE configs[1] shape (224 px, 64 columns, K = 286) at B = 32 and at the bench's B = 256: size-independent
