@@ -183,7 +183,7 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNTArgs& p, f32x16 (&a
 // (the conv-gather two-level kernel would otherwise take 88 registers = 5 waves), plain 128x64 two-level at 4 (120 instead of
 // 140 registers); none of them spills (checked in the ISA: private_segment_fixed_size 0).
 template <int TM, int TN, int BK, bool VEC, bool ACC2 = false, bool PLAIN = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BK == 16 && VEC) ? (TM * TN == 1 ? 6 : ((TM * TN == 2 && ACC2 && PLAIN) ? 4 : 1)) : 1)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BK == 16 && VEC) ? (TM * TN == 1 ? 6 : ((TM * TN == 2 && ACC2 && (PLAIN || TN == 2)) ? 4 : 1)) : 1)))
 void gemm_nt_kernel(GemmNTArgs p) {
   constexpr int BM = 64 * TM, BN = 64 * TN, LS = BK + 4;   // LS = 20 / 36: conflict-free ds_read_b128 (i*LS mod 64 distinct)
   constexpr int KQ = BK / 4, RP = 256 / KQ;                 // float4 per tile row, tile rows per load pass
@@ -608,7 +608,7 @@ static int gemm_nt_attr() {
 // which tile variant stil_gemm_nt launches for an [M,N] output
 extern "C" int stil_gemm_nt_variant(int M, int N, int tune) {
   const int forced = tune % 100;
-  if (forced == 11 || forced == 21 || forced == 22) return forced;
+  if (forced == 11 || forced == 21 || forced == 22 || forced == 12) return forced;
   // measured (tests/tools/gemm_bench.py, profiles/r02t-u): with 6 waves per SIMD the 64x64 tile is at least as fast as
   // 128x64 / 128x128 on every shape of the step (occupancy + tile quantisation over 256 CUs outweigh operand reuse).
   (void)M; (void)N;
@@ -616,7 +616,7 @@ extern "C" int stil_gemm_nt_variant(int M, int N, int tune) {
 }
 
 // rows per output tile of the variant stil_gemm_nt picks for [M,N] (the granularity of `colstats`)
-extern "C" int stil_gemm_nt_tile_rows(int M, int N, int tune) { return stil_gemm_nt_variant(M, N, tune) == 11 ? 64 : 128; }
+extern "C" int stil_gemm_nt_tile_rows(int M, int N, int tune) { const int v = stil_gemm_nt_variant(M, N, tune); return (v == 11 || v == 12) ? 64 : 128; }
 
 // The kernel instantiation stil_gemm_nt launches for these operands, as variant + 100 * bk32 + 1000 * acc2 + 10000 * vec +
 // 100000 * plain (bench bookkeeping: names the rocprofv3 row of a launch).  `plain`: 1x1 / stride 1 / no padding / identity
@@ -637,7 +637,7 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
                             const float* shift, const float* resid, int ldr, float* pre, int act, float alpha,
                             float* colstats, int tune, void* stream) {
   STIL_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0, "stil_gemm_nt: null pointer or empty shape (M=%d N=%d K=%d)", M, N, K);
-  STIL_REQUIRE(tune >= 0 && tune < 3000 && (tune % 100 == 0 || tune % 100 == 11 || tune % 100 == 21 || tune % 100 == 22) && (tune / 100) % 10 <= 1,
+  STIL_REQUIRE(tune >= 0 && tune < 3000 && (tune % 100 == 0 || tune % 100 == 11 || tune % 100 == 21 || tune % 100 == 22 || tune % 100 == 12) && (tune / 100) % 10 <= 1,
                "stil_gemm_nt: bad tune %d", tune);
   STIL_REQUIRE(KH * KW * srcC == K, "stil_gemm_nt: K=%d != KH*KW*C=%d", K, KH * KW * srcC);
   STIL_REQUIRE(M % (OH * OW) == 0, "stil_gemm_nt: M=%d not a multiple of OH*OW=%d", M, OH * OW);
@@ -674,8 +674,9 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
     else hipLaunchKernelGGL((gemm_nt_kernel<TM_, TN_, BK_, V_, false, false>), grid_, dim3(256), lds_, s, p);               \
   } while (0)
   if (!vec) {  // unaligned / ragged operands (K = 286 classifier gradients ...): scalar guarded loads
-    if (variant == 11) LAUNCH_NT(1, 1, 16, false); else if (variant == 21) LAUNCH_NT(2, 1, 16, false); else LAUNCH_NT(2, 2, 16, false);
+    if (variant == 11) LAUNCH_NT(1, 1, 16, false); else if (variant == 21) LAUNCH_NT(2, 1, 16, false); else if (variant == 12) LAUNCH_NT(1, 2, 16, false); else LAUNCH_NT(2, 2, 16, false);
   } else if (variant == 11) { if (bk32) LAUNCH_NT(1, 1, 32, true); else LAUNCH_NT(1, 1, 16, true); }
+  else if (variant == 12) { LAUNCH_NT(1, 2, 16, true); }
   else if (variant == 21) { if (bk32) LAUNCH_NT(2, 1, 32, true); else LAUNCH_NT(2, 1, 16, true); }
   else { if (bk32) LAUNCH_NT(2, 2, 32, true); else LAUNCH_NT(2, 2, 16, true); }
 #undef LAUNCH_NT

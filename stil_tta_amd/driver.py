@@ -123,6 +123,10 @@ class GraphedTrainStep:
     hipGraph and replayed: ~1500 kernel launches per step collapse into one graph launch, which is what matters when
     the per-GPU batch is small (BASELINE config 1: B = 32, config 5: B = 16 per GPU) and eager launches go host-bound.
 
+    With STIL_GRAPH_SIDE=1 the capture keeps the step's two-stream structure (EMA teacher beside the student, weight
+    gradients beside the input-gradient chain: ops._SideStream forks and joins are captured as graph dependencies);
+    the default captures every launch inline (faster for the small per-GPU batches graphs are for, ops._SideStream).
+
     Static shapes only; the batch is copied into static device buffers before each replay.  Everything that varies per
     step lives in device memory (mask-RNG step counter, Adam step counts); what is baked in at capture -- learning rate,
     `current_epoch > start_epoch`, the set of parameters that receive gradients -- is watched, and a change triggers a

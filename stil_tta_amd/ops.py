@@ -62,11 +62,17 @@ class _SideStream:
     """Weight-gradient GEMMs leave the critical path of backward: they only feed the gradient slab, so they run on a
     second HIP stream and overlap the HBM-bound BN / elementwise passes of the layers below (fork = side waits on
     main when the launch is issued; join = main waits on side before anything reads the slab, see join_side()).
-    STIL_WGRAD_STREAM=0 keeps everything on one stream; inside a hipGraph capture the launches stay inline."""
+    STIL_WGRAD_STREAM=0 keeps everything on one stream.  Inside a hipGraph capture the forks and joins are captured too
+    with STIL_GRAPH_SIDE=1 (the side stream joins the capture through wait_stream, events become graph dependencies), so a
+    replayed step keeps both streams' concurrency; the default keeps captured launches inline on the capturing stream,
+    which is what measured faster where graphs pay at all (profiles/r03_experiments.txt: cardiac, 16 samples per GPU:
+    18.2 ms inline / 20.0 ms two-stream / 19.3 ms eager; at B = 256 the two-stream graph beats the inline one, 138 vs 141 ms,
+    and eager beats both at 130 ms)."""
 
     def __init__(self):
         import os
         self.enabled = os.environ.get("STIL_WGRAD_STREAM", "1") != "0"
+        self.in_capture = os.environ.get("STIL_GRAPH_SIDE", "0") != "0"
         self.streams = {}
         # (event recorded on the side stream after a launch, the tensors that launch reads).  Holding the references
         # (1) keeps the autograd engine from accumulating IN PLACE into a gradient buffer a pending side-stream kernel
@@ -77,6 +83,10 @@ class _SideStream:
     def retire(self, everything=False):
         """Drop the references whose side-stream work has completed (or all of them, after a join)."""
         k = self.keep
+        if torch.cuda.is_current_stream_capturing():   # nothing executes during capture and events cannot be queried:
+            if everything:                              # the references live until the join
+                del k[:]
+            return
         i = 0
         while i < len(k) and (everything or k[i][0].query()):
             i += 1
@@ -100,8 +110,10 @@ def join_side():
 
 
 def side_stream(device):
-    """The side stream of `device`, or None when overlap is off / a hipGraph capture is running."""
-    if not _side.enabled or torch.cuda.is_current_stream_capturing() or _prof_active():
+    """The side stream of `device`, or None when overlap is off (or a capture runs with STIL_GRAPH_SIDE=0)."""
+    if not _side.enabled or _prof_active():
+        return None
+    if not _side.in_capture and torch.cuda.is_current_stream_capturing():
         return None
     return _side.get(device)
 

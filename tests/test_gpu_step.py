@@ -528,11 +528,15 @@ def test_empty_and_ragged_inputs_fail_loudly():
         ops.gemm_nt(torch.randn(9, 3, device="cuda"), torch.randn(4, 27, device="cuda"), 9, 4, 27, geom=(3, 3, 3, 3, 3, 3, 3, 1, 1, 0))
 
 
-def test_graphed_step_replays_the_eager_step_bit_for_bit():
-    """hipGraph capture of the whole step (driver.GraphedTrainStep): same kernels, same order -> identical bits,
-    including fresh dropout masks per replay (device-side RNG step counter)."""
-    from stil_tta_amd import STiLModel
+@pytest.mark.parametrize("two_streams", [True, False])
+def test_graphed_step_replays_the_eager_step_bit_for_bit(two_streams):
+    """hipGraph capture of the whole step (driver.GraphedTrainStep): same kernels, same operands -> identical bits,
+    including fresh dropout masks per replay (device-side RNG step counter).  two_streams: the capture keeps the side
+    stream's forks and joins (teacher beside student, weight gradients beside the input-gradient chain) as graph
+    dependencies; False: every captured launch inline on the capturing stream (STIL_GRAPH_SIDE=0)."""
+    from stil_tta_amd import STiLModel, ops
     from stil_tta_amd.driver import train_step, synthetic_batch, GraphedTrainStep
+    ops._side.in_capture = two_streams
     from stil_tta_amd.flat import StilAdam
     fl = [3, 4] + [1] * 3
 
@@ -557,6 +561,7 @@ def test_graphed_step_replays_the_eager_step_bit_for_bit():
     assert torch.equal(me.flat.params, mg.flat.params) and torch.equal(me.flat.ema, mg.flat.ema)
     assert torch.equal(me.prototypes_sum, mg.prototypes_sum)
     assert any(not torch.equal(masks_seen[0], m_) for m_ in masks_seen[1:]), "replays must draw fresh random masks"
+    ops._side.in_capture = False
 
 
 def test_side_stream_pipeline_is_bit_exact():
