@@ -46,9 +46,13 @@ int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, 
                  int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad_y, int pad_x,
                  int mode, int out_stride, int out_py, int out_px, int out_OH, int out_OW,
                  const float* bias, const float* sub, const float* scale, const float* shift, const float* resid,
-                 int ldr, float* pre, int act, float alpha, float* colstats, int tune, void* stream);
-/* `tune` (0 = automatic; otherwise for A/B measurements) = variant + 100 * bk32 + 1000 * acc2:
- *   variant  block tile: 22 = 128x128, 21 = 128x64, 11 = 64x64 (0: automatic = 64x64, the fastest on every shape of the step);
+                 int ldr, float* pre, int act, float alpha, float* colstats, const float* a_bn, int tune, void* stream);
+/* `a_bn` (optional; forward gathers with srcC % 16 == 0, 16-byte aligned operands): the A source is the RAW output y of a
+ *   training conv+BN+ReLU layer and a_bn that layer's statistics block [4][srcC] (mean, rstd, a = gamma * rstd, beta, as
+ *   stil_bn_train_fwd_tiles writes it); z = relu((y - mean) * a + beta) is formed while A is staged, so the inner layers of a
+ *   residual block never materialise z (models/resnets.py:112-132: bn1/relu, bn2/relu fused into conv2 / conv3).
+ * `tune` (0 = automatic; otherwise for A/B measurements) = variant + 100 * bk32 + 1000 * acc2:
+ *   variant  block tile: 22 = 128x128, 21 = 128x64, 12 = 64x128, 11 = 64x64 (0: automatic = 64x64, the fastest on the shapes of the step);
  *   bk32     1 = 32-deep LDS k-tiles instead of 16;
  *   acc2     two-level accumulation (partial chains of 64 products added to a master accumulator, ~ATen-CPU's
  *            rounding noise for long reductions): 0 = for K >= 512, 1 = never, 2 = always.
@@ -57,8 +61,8 @@ int stil_gemm_nt_tile_rows(int M, int N, int tune);
 int stil_gemm_nt_variant(int M, int N, int tune);
 /* the instantiation stil_gemm_nt launches for these operands: variant + 100 * bk32 + 1000 * acc2 + 10000 * vec (16-byte
  * loads) + 100000 * plain (`plain` = 1: 1x1 / stride 1 / no padding / identity output map -- A is a plain row-major matrix
- * and the kernel's geometry code is compiled out) */
-int stil_gemm_nt_config(const float* A, const float* W, int M, int N, int K, int lda, int ldb, int srcC, int KH, int KW, int plain, int tune);
+ * and the kernel's geometry code is compiled out) + 1000000 * a_bn (the operand-staging BatchNorm instantiation) */
+int stil_gemm_nt_config(const float* A, const float* W, int M, int N, int K, int lda, int ldb, int srcC, int KH, int KW, int plain, int a_bn, int tune);
 
 /* Weight gradient  dW (+)= dY[M,N]^T . Xgather[M,K]  (split over M, slab partials + ordered reduce).
  * KH*KW > 1: dW is written in the reference layout (N, srcC, KH, KW); else [N, Kdst] (first Kdst columns).
@@ -66,7 +70,9 @@ int stil_gemm_nt_config(const float* A, const float* W, int M, int N, int K, int
 size_t stil_wgrad_workspace_bytes(int M, int N, int K, int tune);
 int stil_wgrad_tn(const float* dY, const float* X, float* dW, int M, int N, int K, int ldy, int ldx,
                   int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad,
-                  int Kdst, int accumulate, float* workspace, size_t workspace_bytes, int tune, void* stream);
+                  int Kdst, int accumulate, const float* x_bn, float* workspace, size_t workspace_bytes, int tune, void* stream);
+/* `x_bn` (optional): as stil_gemm_nt's a_bn, for the X operand (the raw conv output of the producing layer and its
+ * statistics block [4][srcC]). */
 
 /* out[n] (+)= scale * sum_m X[m,n]   (bias gradients) */
 size_t stil_colsum_workspace_bytes(int M, int N);
@@ -86,6 +92,8 @@ int stil_transpose(const float* in, float* out, int R, int C, void* stream);
 /* ---- BatchNorm2d (NHWC rows), ReLU, residual, max-pool: models/resnets.py:112-132,248-252 ----
  * stats: [4,C] = mean, rstd, a=gamma*rstd, beta (z = (x-mean)*a + beta); bn_eval_affine's ab: [3,C] = a, beta, running_mean.  Train forward also updates the running
  * statistics (momentum, unbiased variance) and num_batches_tracked. z = relu?(x*a + b + resid).
+ * stil_bn_train_fwd_tiles with z == NULL computes the statistics only (running buffers, `stats`): the consumer applies
+ * them while it stages its operand (stil_gemm_nt a_bn / stil_wgrad_tn x_bn).
  * bn_train_bwd's relu: 0 = none, 1 = mask (z > 0) read from z, 2 = mask recomputed from x and stats (only without
  * a residual input; z may then be NULL).  gout (optional) receives dz*mask, the gradient of the residual branch. */
 size_t stil_bn_workspace_bytes(int M, int C);

@@ -64,7 +64,8 @@ class GradExchange:
         self.plans: Dict[object, Optional[Tuple[List[int], List[int]]]] = {}
         self.comm_stream: Optional[torch.cuda.Stream] = None
         self.active = False
-        self._check = None            # (work, tensor, what) of the step-opening agreement all-reduce, verified lazily
+        self._check = None            # (work / event, result words, what) of the step-opening agreement all-reduce, verified lazily
+        self._chk = None              # pinned in / device / pinned out buffers of that agreement (GPU runs)
         self._reset(None)
 
     def _reset(self, sig):
@@ -92,6 +93,7 @@ class GradExchange:
         if t.is_cuda:
             if self.comm_stream is None:
                 self.comm_stream = torch.cuda.Stream(t.device)
+            self.comm_stream.wait_stream(torch.cuda.current_stream(t.device))   # `t` was produced on the current stream
             with torch.cuda.stream(self.comm_stream):
                 return fn(t)
         return fn(t)
@@ -101,21 +103,44 @@ class GradExchange:
         return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 
     def _open_check(self):
-        """Every rank must be at the same signature and in the same mode (learning / post-backward vs overlap)."""
+        """Every rank must be at the same signature and in the same mode (learning / post-backward vs overlap).
+        Nothing here blocks the host or the main stream: the four words travel host -> device on the main stream (pinned,
+        non-blocking), are MAX-all-reduced on the communication stream and come back into pinned host memory on that
+        stream; verify() reads them one step later (or at once on a learning step)."""
         import zlib
         h = zlib.crc32(repr(self.sig).encode()) & 0x7fffffff
         mode = 0 if self.expect is None else 1
-        t = torch.tensor([h, -h, mode, -mode], dtype=torch.int64, device=self.flat._grads.device)
-        wk = self._comm(lambda x: dist.all_reduce(x, op=dist.ReduceOp.MAX, async_op=True), t)
-        self._check = (wk, t, f"signature {self.sig!r}, mode {'overlap' if mode else 'post-backward'}")
+        what = f"signature {self.sig!r}, mode {'overlap' if mode else 'post-backward'}"
+        dev = self.flat._grads.device
+        vals = torch.tensor([h, -h, mode, -mode], dtype=torch.int64)
+        if dev.type != "cuda":
+            wk = dist.all_reduce(vals, op=dist.ReduceOp.MAX, async_op=True)
+            self._check = (wk, vals, what)
+            return
+        if self._chk is None:
+            self._chk = (torch.empty(4, dtype=torch.int64).pin_memory(), torch.empty(4, dtype=torch.int64, device=dev),
+                         torch.empty(4, dtype=torch.int64).pin_memory())
+        pin_in, t, pin_out = self._chk
+        pin_in.copy_(vals)
+        t.copy_(pin_in, non_blocking=True)                              # main stream, asynchronous
+        if self.comm_stream is None:
+            self.comm_stream = torch.cuda.Stream(dev)
+        cs = self.comm_stream
+        cs.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(cs):
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, async_op=True).wait()   # cs waits for the collective
+            pin_out.copy_(t, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(cs)
+        self._check = (ev, pin_out, what)
 
     def verify(self):
-        """Host check of the last step-opening agreement (reads 4 words; the collective was the first one of its step)."""
+        """Host check of the last step-opening agreement (4 words; the collective was the first one of its step)."""
         if self._check is None:
             return
         wk, t, what = self._check
         self._check = None
-        wk.wait()
+        wk.synchronize() if isinstance(wk, torch.cuda.Event) else wk.wait()
         v = t.tolist()
         if v[0] != -v[1] or v[2] != -v[3]:
             raise RuntimeError(f"data-parallel ranks disagree on the gradient exchange of this step (this rank: {what}; "
@@ -203,11 +228,13 @@ class GradExchange:
         learned = None
         if self.expect is None:
             # post-backward exchange: EVERY bucket, in index order -- the same sequence on every rank whatever its
-            # autograd engine did.  First make sure all ranks are here in this mode (a rare step: the host read is free).
-            if not self._capturing():
+            # autograd engine did.  On a LEARNING step first make sure all ranks are here in this mode (a rare step: the
+            # host read is free); steady post-backward steps are verified one step later, like overlap steps.
+            learning = self.sig is not None and self.enabled and self.sig not in self.plans
+            if learning and not self._capturing():
                 self.verify()
             pending = list(range(len(self.ranges)))
-            if self.sig is not None and self.enabled and self.sig not in self.plans:
+            if learning:
                 # buckets that received gradients, ordered by their LAST contribution (the order they can leave in next time)
                 learned = (list(self.counts), sorted(self.last_touch, key=self.last_touch.get))
         else:

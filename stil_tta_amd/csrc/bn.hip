@@ -452,7 +452,8 @@ extern "C" int stil_bn_train_fwd_tiles(const float* x, const float* tilestats, i
                                        float* running_mean, float* running_var, long long* num_batches_tracked,
                                        const float* resid, float* z, float* stats, int M, int C, int relu, float eps,
                                        float momentum, void* workspace, size_t workspace_bytes, void* stream) {
-  STIL_REQUIRE(x && tilestats && gamma && beta && z && stats && workspace, "stil_bn_train_fwd_tiles: null pointer");
+  STIL_REQUIRE(x && tilestats && gamma && beta && stats && workspace, "stil_bn_train_fwd_tiles: null pointer");
+  STIL_REQUIRE(z || !resid, "stil_bn_train_fwd_tiles: statistics-only call (z == NULL) cannot take a residual");
   STIL_REQUIRE(tile_rows > 0 && M > 0 && C % 4 == 0, "stil_bn_train_fwd_tiles: bad shape M=%d C=%d tile_rows=%d", M, C, tile_rows);
   STIL_REQUIRE(workspace_bytes >= stil_bn_tiles_workspace_bytes(M, C, tile_rows) && ((uintptr_t)workspace % 8) == 0,
                "stil_bn_train_fwd_tiles: workspace too small or not 8-byte aligned");
@@ -464,6 +465,7 @@ extern "C" int stil_bn_train_fwd_tiles(const float* x, const float* tilestats, i
   hipLaunchKernelGGL(bn_tiles_stage2_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)workspace, nsplit, M, C, gamma, beta,
                      running_mean, running_var, num_batches_tracked, stats, eps, momentum);
   STIL_LAUNCH_CHECK();
+  if (!z) return STIL_OK;   // statistics only: the consumer applies them while it stages its operand
   long total4 = (long)M * C / 4;
   int grid = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, s, x, stats, resid, z, total4, C, relu);

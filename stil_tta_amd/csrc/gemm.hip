@@ -48,6 +48,10 @@ struct GemmNTArgs {
   // optional per-tile column statistics of the stored output (training BatchNorm without a statistics pass over C):
   // colstats[(tm*2 + 0)*N + col] = mean over the tile's valid rows, [(tm*2 + 1)*N + col] = sum of squared deviations
   float* colstats;
+  // optional training-BatchNorm + ReLU of the PRODUCING layer applied to the A operand as it is staged (the consumer conv
+  // of a bottleneck reads the raw conv output y of the layer before it; z = relu((y - mean) * a + beta) is never
+  // materialised): abn = that layer's statistics block [4][C] = mean, rstd, a = gamma * rstd, beta (bn.hip)
+  const float* abn;
 };
 
 __device__ __forceinline__ float4 ld4_guard(const float* p, int nvalid, int vec) {
@@ -182,7 +186,11 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNTArgs& p, f32x16 (&a
 // amdgpu_waves_per_eu: a register budget for the instantiations the step spends its time in -- 64x64 tiles at 6 waves per SIMD
 // (the conv-gather two-level kernel would otherwise take 88 registers = 5 waves), plain 128x64 two-level at 4 (120 instead of
 // 140 registers); none of them spills (checked in the ISA: private_segment_fixed_size 0).
-template <int TM, int TN, int BK, bool VEC, bool ACC2 = false, bool PLAIN = false>
+// BNA: the A operand is the raw output of a training conv+BN+ReLU layer; its BatchNorm + ReLU are applied between the
+// global load and the LDS store (per-channel mean / a / beta from a 3 x C table staged in LDS once per workgroup; the
+// zero padding of a conv gather stays zero).  Same arithmetic as bn_apply_kernel, so the products are those of the
+// materialised path bit for bit.
+template <int TM, int TN, int BK, bool VEC, bool ACC2 = false, bool PLAIN = false, bool BNA = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BK == 16 && VEC) ? (TM * TN == 1 ? 6 : ((TM * TN == 2 && ACC2 && (PLAIN || TN == 2)) ? 4 : 1)) : 1)))
 void gemm_nt_kernel(GemmNTArgs p) {
   constexpr int BM = 64 * TM, BN = 64 * TN, LS = BK + 4;   // LS = 20 / 36: conflict-free ds_read_b128 (i*LS mod 64 distinct)
@@ -191,6 +199,7 @@ void gemm_nt_kernel(GemmNTArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 * (BM + BN) * LS floats
   float* As = lds;
   float* Bs = lds + 2 * BM * LS;
+  float* tab = lds + 2 * (BM + BN) * LS;   // BNA: [3][C] = mean, a, beta of the producing layer
 
   const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
   const int wg = xcd_remap(blockIdx.x, nbm * nbn);
@@ -228,6 +237,16 @@ void gemm_nt_kernel(GemmNTArgs p) {
   float4 ra[RA], rb[RB];
   const float* a_src[RA];
   bool a_val[RA];
+  bool ra_ok[RA];   // BNA: which of the staged A quads are real data (padding / out-of-range rows must stay zero)
+  int ra_c = 0;     // BNA: channel of the staged quad's first element
+  if constexpr (BNA) {
+    const int C = p.g.C;
+    for (int i = threadIdx.x; i < 3 * C; i += 256) {
+      const int r = i / C, c = i - r * C;
+      tab[i] = p.abn[(r == 0 ? 0 : r + 1) * C + c];
+    }
+    __syncthreads();
+  }
   auto set_tap = [&](int tap) {
     if constexpr (PLAIN) {
 #pragma unroll
@@ -261,10 +280,12 @@ void gemm_nt_kernel(GemmNTArgs p) {
   set_tap(0);
   auto gload = [&]() {
     const int nval = g.C - (c0 + kq * 4);   // <= 0 only in the K tail of a plain GEMM (C == K, K % BK != 0)
+    if constexpr (BNA) ra_c = c0 + kq * 4;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       if (VEC) ra[i] = ld4_sel(a_src[i] + c0, p.A, a_val[i] && nval > 0);
       else ra[i] = a_val[i] ? ld4_guard(a_src[i] + c0, nval, 0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (BNA) ra_ok[i] = a_val[i] && nval > 0;
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
@@ -279,6 +300,19 @@ void gemm_nt_kernel(GemmNTArgs p) {
     }
   };
   auto lstore = [&](int buf) {
+    if constexpr (BNA) {   // z = relu((y - mean) * a + beta), exactly as bn_apply_kernel computes it
+      const int C = p.g.C;
+      const float4 mu = *reinterpret_cast<const float4*>(tab + ra_c);
+      const float4 aa = *reinterpret_cast<const float4*>(tab + C + ra_c);
+      const float4 bb = *reinterpret_cast<const float4*>(tab + 2 * C + ra_c);
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        float4 v = ra[i];
+        v.x = (v.x - mu.x) * aa.x + bb.x; v.y = (v.y - mu.y) * aa.y + bb.y; v.z = (v.z - mu.z) * aa.z + bb.z; v.w = (v.w - mu.w) * aa.w + bb.w;
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        ra[i] = ra_ok[i] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < RA; ++i)
       *reinterpret_cast<float4*>(&As[buf * BM * LS + (r0 + RP * i) * LS + kq * 4]) = ra[i];
@@ -305,6 +339,11 @@ void gemm_nt_kernel(GemmNTArgs p) {
     constexpr bool FULL = decltype(full_tag)::value;
     auto load = [&]() {
       if constexpr (FULL) {
+        if constexpr (BNA) {
+          ra_c = c0 + kq * 4;
+#pragma unroll
+          for (int i = 0; i < RA; ++i) ra_ok[i] = true;
+        }
 #pragma unroll
         for (int i = 0; i < RA; ++i) ra[i] = *reinterpret_cast<const float4*>(a_src[i] + c0);
 #pragma unroll
@@ -403,9 +442,11 @@ struct GemmTNArgs {
   ConvGeom g;
   int m_per_split;
   int vecY, vecX;
+  const float* xbn;   // optional: X is the raw output y of a training conv+BN+ReLU layer; relu((y - mean) * a + beta) is applied
+                      // while X is staged (statistics block [4][C] of that layer), see GemmNTArgs::abn
 };
 
-template <int TNn, int TK, bool VEC>
+template <int TNn, int TK, bool VEC, bool XBN = false>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p) {
   constexpr int BN = 64 * TNn, BKo = 64 * TK, BMr = 16;
   constexpr int Y4 = BN / 4, X4 = BKo / 4;            // float4 per row
@@ -434,6 +475,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p) {
   const int ohw = g.OH * g.OW;
 
   float4 ry[YP], rx[XP];
+  bool rx_ok[XP];
+  float4 xmu, xa, xb;   // XBN: this thread's four channels never change (its k column is fixed over the m loop)
+  if constexpr (XBN) {
+    const int cc = xk < p.K ? xcch : 0;
+    xmu = *reinterpret_cast<const float4*>(p.xbn + cc);
+    xa = *reinterpret_cast<const float4*>(p.xbn + 2 * g.C + cc);
+    xb = *reinterpret_cast<const float4*>(p.xbn + 3 * g.C + cc);
+  }
   // row decode (m -> n, oy, ox) is done once and then advanced incrementally by BMr rows per iteration
   const bool plain = (g.KH * g.KW == 1) && g.stride == 1 && g.pad_y == 0 && g.pad_x == 0 && g.OH == g.H && g.OW == g.W;
   int x_n[XP], x_oy[XP], x_ox[XP];
@@ -467,12 +516,22 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p) {
       }
       if (VEC) rx[i] = ld4_sel(src, p.X, ok);
       else rx[i] = ok ? ld4_guard(src, p.K - xk, 0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (XBN) rx_ok[i] = ok;
     }
   };
   auto lstore = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < YP; ++i)
       *reinterpret_cast<float4*>(&Ys[buf * BMr * BN + (yr + YR * i) * BN + yc * 4]) = ry[i];
+    if constexpr (XBN) {   // z = relu((y - mean) * a + beta) as bn_apply_kernel computes it; padding stays zero
+#pragma unroll
+      for (int i = 0; i < XP; ++i) {
+        float4 v = rx[i];
+        v.x = (v.x - xmu.x) * xa.x + xb.x; v.y = (v.y - xmu.y) * xa.y + xb.y; v.z = (v.z - xmu.z) * xa.z + xb.z; v.w = (v.w - xmu.w) * xa.w + xb.w;
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        rx[i] = rx_ok[i] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < XP; ++i)
       *reinterpret_cast<float4*>(&Xs[buf * BMr * BKo + (xr + XR * i) * BKo + xc * 4]) = rx[i];
@@ -619,14 +678,16 @@ extern "C" int stil_gemm_nt_variant(int M, int N, int tune) {
 extern "C" int stil_gemm_nt_tile_rows(int M, int N, int tune) { const int v = stil_gemm_nt_variant(M, N, tune); return (v == 11 || v == 12) ? 64 : 128; }
 
 // The kernel instantiation stil_gemm_nt launches for these operands, as variant + 100 * bk32 + 1000 * acc2 + 10000 * vec +
-// 100000 * plain (bench bookkeeping: names the rocprofv3 row of a launch).  `plain`: 1x1 / stride 1 / no padding / identity
+// 100000 * plain + 1000000 * a_bn (bench bookkeeping: names the rocprofv3 row of a launch).  `plain`: 1x1 / stride 1 / no padding / identity
 // output map, i.e. A is a plain row-major matrix.  The launcher below calls the same function.
 extern "C" int stil_gemm_nt_config(const float* A, const float* W, int M, int N, int K, int lda, int ldb, int srcC, int KH, int KW,
-                                   int plain, int tune) {
+                                   int plain, int a_bn, int tune) {
   const int variant = stil_gemm_nt_variant(M, N, tune);
   const bool bk32 = (tune / 100) % 10 == 1 && (K % 32 == 0) && (KH * KW == 1 || srcC % 32 == 0);
   const bool acc2 = tune / 1000 == 2 || (tune / 1000 == 0 && K >= 512);
   const bool vec = is_vec(A, lda) && (srcC % 4 == 0) && is_vec(W, ldb) && (K % 4 == 0);  // every 16-byte load aligned and entirely in or out
+  if (a_bn)   // operand-staging BatchNorm: 64x64 tiles, BK = 16 (see stil_gemm_nt)
+    return 11 + 1000 * (acc2 ? 1 : 0) + 10000 * (vec ? 1 : 0) + 100000 * ((plain && KH * KW == 1) ? 1 : 0) + 1000000;
   return variant + 100 * ((vec && bk32) ? 1 : 0) + 1000 * (acc2 ? 1 : 0) + 10000 * (vec ? 1 : 0) + 100000 * ((plain && KH * KW == 1) ? 1 : 0);
 }
 
@@ -635,7 +696,7 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
                             int pad_x, int mode, int out_stride, int out_py, int out_px, int out_OH, int out_OW,
                             const float* bias, const float* sub, const float* scale,
                             const float* shift, const float* resid, int ldr, float* pre, int act, float alpha,
-                            float* colstats, int tune, void* stream) {
+                            float* colstats, const float* a_bn, int tune, void* stream) {
   STIL_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0, "stil_gemm_nt: null pointer or empty shape (M=%d N=%d K=%d)", M, N, K);
   STIL_REQUIRE(tune >= 0 && tune < 3000 && (tune % 100 == 0 || tune % 100 == 11 || tune % 100 == 21 || tune % 100 == 22 || tune % 100 == 12) && (tune / 100) % 10 <= 1,
                "stil_gemm_nt: bad tune %d", tune);
@@ -648,6 +709,7 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   p.bias = bias; p.sub = sub; p.scale = scale; p.shift = shift; p.resid = resid; p.ldr = ldr; p.pre = pre; p.act = act;
   p.alpha = alpha;
   p.colstats = colstats;
+  p.abn = a_bn;
   STIL_REQUIRE(!colstats || (p.os == 1 && !bias && !sub && !scale && !shift && !resid && act == 0),
                "stil_gemm_nt: colstats describes the raw product (no bias / affine / residual / activation / output map)");
   p.vecA = is_vec(A, lda) && (srcC % 4 == 0);
@@ -657,13 +719,25 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   hipStream_t s = (hipStream_t)stream;
   // plain row-major A and identity output map: the geometry code is compiled out (gemm_nt_kernel<..., PLAIN>)
   const bool plain = KH * KW == 1 && stride == 1 && pad_y == 0 && pad_x == 0 && mode == 0 && p.os == 1 && srcH == OH && srcW == OW;
-  const int cfg = stil_gemm_nt_config(A, W, M, N, K, lda, ldb, srcC, KH, KW, plain ? 1 : 0, tune);
+  const int cfg = stil_gemm_nt_config(A, W, M, N, K, lda, ldb, srcC, KH, KW, plain ? 1 : 0, a_bn ? 1 : 0, tune);
   const int variant = cfg % 100;
   const bool bk32 = (cfg / 100) % 10 == 1;   // BK = 32 halves the barriers per MFMA; needs whole taps and vector loads
   const bool acc2 = (cfg / 1000) % 10 == 1;  // long reductions: two-level accumulation (see gemm_nt_kernel)
   const bool vec = (cfg / 10000) % 10 == 1;
   rc = gemm_nt_attr();
   if (rc) return rc;
+  if (a_bn) {   // BatchNorm + ReLU of the producing layer applied while A is staged: 64x64 tiles, vector loads, BK = 16 only
+    STIL_REQUIRE(vec && !bk32 && mode == 0 && srcC % 16 == 0 && srcC <= 2048 && (variant == 11 || tune % 100 == 0),
+                 "stil_gemm_nt: a_bn needs 16-byte aligned operands, a forward gather, Cin %% 16 == 0 and Cin <= 2048 (Cin=%d)", srcC);
+    const dim3 grid_(cdiv(M, 64) * cdiv(N, 64));
+    const size_t lds_ = (size_t)2 * 64 * 2 * 20 * sizeof(float) + (size_t)3 * srcC * sizeof(float);
+    if (acc2 && plain) hipLaunchKernelGGL((gemm_nt_kernel<1, 1, 16, true, true, true, true>), grid_, dim3(256), lds_, s, p);
+    else if (acc2) hipLaunchKernelGGL((gemm_nt_kernel<1, 1, 16, true, true, false, true>), grid_, dim3(256), lds_, s, p);
+    else if (plain) hipLaunchKernelGGL((gemm_nt_kernel<1, 1, 16, true, false, true, true>), grid_, dim3(256), lds_, s, p);
+    else hipLaunchKernelGGL((gemm_nt_kernel<1, 1, 16, true, false, false, true>), grid_, dim3(256), lds_, s, p);
+    STIL_LAUNCH_CHECK();
+    return STIL_OK;
+  }
 #define LAUNCH_NT(TM_, TN_, BK_, V_)                                                                          \
   do {                                                                                                        \
     const dim3 grid_(cdiv(M, 64 * TM_) * cdiv(N, 64 * TN_));                                                  \
@@ -710,7 +784,7 @@ extern "C" size_t stil_wgrad_workspace_bytes(int M, int N, int K, int tune) {
 // dW (+)= dY^T . Xgather ; dW laid out [N, Kdst] (taps==1) or (N, Cin, KH, KW) (taps>1)
 extern "C" int stil_wgrad_tn(const float* dY, const float* X, float* dW, int M, int N, int K, int ldy, int ldx,
                              int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad,
-                             int Kdst, int accumulate, float* workspace, size_t workspace_bytes, int tune, void* stream) {
+                             int Kdst, int accumulate, const float* x_bn, float* workspace, size_t workspace_bytes, int tune, void* stream) {
   STIL_REQUIRE(dY && X && dW && workspace, "stil_wgrad_tn: null pointer");
   STIL_REQUIRE(tune == 0 || tune == 11 || tune == 22, "stil_wgrad_tn: bad tune %d", tune);
   STIL_REQUIRE(KH * KW * srcC == K, "stil_wgrad_tn: K=%d != KH*KW*C=%d", K, KH * KW * srcC);
@@ -726,19 +800,24 @@ extern "C" int stil_wgrad_tn(const float* dY, const float* X, float* dW, int M, 
   p.m_per_split = mps;
   p.vecY = is_vec(dY, ldy);
   p.vecX = is_vec(X, ldx) && (srcC % 4 == 0);
+  p.xbn = x_bn;
   hipStream_t s = (hipStream_t)stream;
   const bool vec = p.vecY && p.vecX && (N % 4 == 0) && (K % 4 == 0);
+  STIL_REQUIRE(!x_bn || (vec && srcC % 4 == 0), "stil_wgrad_tn: x_bn needs 16-byte aligned operands and Cin %% 4 == 0");
   if (tn_variant(N, K, tune) == 11) {
     dim3 grid(cdiv(N, 64) * cdiv(K, 64) * splits);
-    if (vec) hipLaunchKernelGGL((gemm_tn_kernel<1, 1, true>), grid, dim3(256), 0, s, p);
+    if (x_bn) hipLaunchKernelGGL((gemm_tn_kernel<1, 1, true, true>), grid, dim3(256), 0, s, p);
+    else if (vec) hipLaunchKernelGGL((gemm_tn_kernel<1, 1, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((gemm_tn_kernel<1, 1, false>), grid, dim3(256), 0, s, p);
   } else if (N <= 64) {
     dim3 grid(cdiv(N, 64) * cdiv(K, 128) * splits);
-    if (vec) hipLaunchKernelGGL((gemm_tn_kernel<1, 2, true>), grid, dim3(256), 0, s, p);
+    if (x_bn) hipLaunchKernelGGL((gemm_tn_kernel<1, 2, true, true>), grid, dim3(256), 0, s, p);
+    else if (vec) hipLaunchKernelGGL((gemm_tn_kernel<1, 2, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((gemm_tn_kernel<1, 2, false>), grid, dim3(256), 0, s, p);
   } else {
     dim3 grid(cdiv(N, 128) * cdiv(K, 128) * splits);
-    if (vec) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, true>), grid, dim3(256), 0, s, p);
+    if (x_bn) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, true, true>), grid, dim3(256), 0, s, p);
+    else if (vec) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, false>), grid, dim3(256), 0, s, p);
   }
   STIL_LAUNCH_CHECK();

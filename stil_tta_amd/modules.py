@@ -56,17 +56,22 @@ def set_teacher_pipe(pipe: Optional[TeacherPipe]):
     _PIPE = pipe
 
 
-def _conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool, train: bool, resid=None, stem=None, passthrough=False):
+def _conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool, train: bool, resid=None, stem=None, passthrough=False, defer=False,
+             xstats=None):
     """passthrough (first conv of a residual block): -> (out, alias of x) so the identity branch's gradient is folded
-    into this conv's input-gradient GEMM (ops.ConvBnActFn)."""
+    into this conv's input-gradient GEMM (ops.ConvBnActFn).
+    defer (training, inner layers of a block): -> (..., stats) with out = the RAW conv output; the next conv gets them as
+    `xstats` and applies this layer's BatchNorm + ReLU while it stages its operand (the student's bn1 / bn2 of
+    models/resnets.py:112-132 fused into conv2 / conv3)."""
     k, stride, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
     pipe = _PIPE
     if train:
         out = ops.ConvBnActFn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                    bn.num_batches_tracked, resid, k, stride, pad, relu, stem, passthrough)
+                                    bn.num_batches_tracked, resid, k, stride, pad, relu, stem, passthrough, defer, xstats)
         if pipe is not None:
             pipe.published()
         return out
+    assert not defer and xstats is None
     if pipe is not None:
         pipe.before_teacher_bn(bn)
     out = ops.conv_bn_eval(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, resid, k, stride, pad,
@@ -88,12 +93,21 @@ class Bottleneck(nn.Module):  # models/resnets.py:91-132
         self.downsample = downsample
 
     def run(self, x, train):
-        out, identity = _conv_bn(x, self.conv1, self.bn1, True, train, passthrough=True)
-        out = _conv_bn(out, self.conv2, self.bn2, True, train)
+        d1 = train and ops.can_defer_bn(self.conv1.out_channels)   # bn1 + relu applied inside conv2's operand staging
+        d2 = train and ops.can_defer_bn(self.conv2.out_channels)   # bn2 + relu applied inside conv3's operand staging
+        st1 = st2 = None
+        if d1:
+            out, identity, st1 = _conv_bn(x, self.conv1, self.bn1, True, train, passthrough=True, defer=True)
+        else:
+            out, identity = _conv_bn(x, self.conv1, self.bn1, True, train, passthrough=True)
+        if d2:
+            out, st2 = _conv_bn(out, self.conv2, self.bn2, True, train, defer=True, xstats=st1)
+        else:
+            out = _conv_bn(out, self.conv2, self.bn2, True, train, xstats=st1)
         if self.downsample is not None:
             identity = _conv_bn(identity, self.downsample[0], self.downsample[1], False, train)
         Nb, H, W, C = identity.shape
-        return _conv_bn(out, self.conv3, self.bn3, True, train, resid=identity.reshape(Nb * H * W, C))
+        return _conv_bn(out, self.conv3, self.bn3, True, train, resid=identity.reshape(Nb * H * W, C), xstats=st2)
 
 
 class BasicBlock(nn.Module):  # models/resnets.py:50-88
@@ -108,11 +122,15 @@ class BasicBlock(nn.Module):  # models/resnets.py:50-88
         self.downsample = downsample
 
     def run(self, x, train):
-        out, identity = _conv_bn(x, self.conv1, self.bn1, True, train, passthrough=True)
+        st1 = None
+        if train and ops.can_defer_bn(self.conv1.out_channels):     # bn1 + relu applied inside conv2's operand staging
+            out, identity, st1 = _conv_bn(x, self.conv1, self.bn1, True, train, passthrough=True, defer=True)
+        else:
+            out, identity = _conv_bn(x, self.conv1, self.bn1, True, train, passthrough=True)
         if self.downsample is not None:
             identity = _conv_bn(identity, self.downsample[0], self.downsample[1], False, train)
         Nb, H, W, C = identity.shape
-        return _conv_bn(out, self.conv2, self.bn2, True, train, resid=identity.reshape(Nb * H * W, C))
+        return _conv_bn(out, self.conv2, self.bn2, True, train, resid=identity.reshape(Nb * H * W, C), xstats=st1)
 
 
 class ResNet(nn.Module):

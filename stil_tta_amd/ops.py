@@ -151,7 +151,7 @@ def _grad_into(param: torch.Tensor, writer):
 
 # ------------------------------------------------------------------------------------------ raw wrappers
 def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None, bias=None, sub=None, scale=None, shift=None,
-            resid=None, pre=None, act=0, alpha=1.0, pads=None, outmap=None, out_rows=None, colstats=None):
+            resid=None, pre=None, act=0, alpha=1.0, pads=None, outmap=None, out_rows=None, colstats=None, a_bn=None):
     """C = epilogue(alpha * Agather . W^T).  geom = (srcH, srcW, srcC, OH, OW, KH, KW, stride, pad, mode);
     pads = (pad_y, pad_x) overrides geom's pad; outmap = (out_stride, py, px, out_OH, out_OW) scatters GEMM row
     (n, oy, ox) to output row (n*out_OH + oy*s + py)*out_OW + ox*s + px (out_rows = rows of `out` then)."""
@@ -172,15 +172,15 @@ def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None,
         nbytes = 4.0 * (src + N * K + M * N * (1 + (resid is not None) + (pre is not None)))
         plain = int(geom[5] * geom[6] == 1 and geom[7] == 1 and pads == (0, 0) and geom[9] == 0 and outmap[0] == 1
                     and geom[0] == geom[3] and geom[1] == geom[4])
-        cfg = L.gemm_nt_config(_p(A), _p(W), M, N, K, lda, ldb, geom[2], geom[5], geom[6], plain, TUNE["gemm"])
+        cfg = L.gemm_nt_config(_p(A), _p(W), M, N, K, lda, ldb, geom[2], geom[5], geom[6], plain, int(a_bn is not None), TUNE["gemm"])
         meta = (cfg, 2.0 * M * N * K / s2, (M, N, K, geom[5], geom[7], geom[9]), nbytes)
     L.gemm_nt(_p(A), _p(W), _p(out), M, N, K, lda, ldb, ldc, *geom[:8], pads[0], pads[1], geom[9], *outmap,
               _p(bias), _p(sub), _p(scale), _p(shift), _p(resid),
-              (ldc if resid is not None else 0), _p(pre), act, float(alpha), _p(colstats), TUNE["gemm"], _stream(), meta=meta)
+              (ldc if resid is not None else 0), _p(pre), act, float(alpha), _p(colstats), _p(a_bn), TUNE["gemm"], _stream(), meta=meta)
     return out
 
 
-def wgrad_tn(dY, X, dW, M, N, K, *, ldy=None, ldx=None, geom=None, Kdst=None, accumulate=0):
+def wgrad_tn(dY, X, dW, M, N, K, *, ldy=None, ldx=None, geom=None, Kdst=None, accumulate=0, x_bn=None):
     if geom is None:
         geom = (1, 1, K, 1, 1, 1, 1, 1, 0)
     ldy = N if ldy is None else ldy
@@ -190,7 +190,7 @@ def wgrad_tn(dY, X, dW, M, N, K, *, ldy=None, ldx=None, geom=None, Kdst=None, ac
     w = _ws.get(nb, dY.device)
     L = lib()
     meta = (0, 2.0 * M * N * K, (M, N, K, geom[5], geom[7], 2)) if L._prof is not None else None
-    L.wgrad_tn(_p(dY), _p(X), _p(dW), M, N, K, ldy, ldx, *geom, Kdst, accumulate, _p(w), nb, TUNE["wgrad"], _stream(), meta=meta)
+    L.wgrad_tn(_p(dY), _p(X), _p(dW), M, N, K, ldy, ldx, *geom, Kdst, accumulate, _p(x_bn), _p(w), nb, TUNE["wgrad"], _stream(), meta=meta)
 
 
 def wgrad_param(param, dY, X, M, N, K, **kw):
@@ -209,7 +209,7 @@ def wgrad_param(param, dY, X, M, N, K, **kw):
         if main != side:
             ev = torch.cuda.Event()
             ev.record(side)
-            _side.keep.append((ev, (dY, X)))
+            _side.keep.append((ev, (dY, X, kw.get("x_bn"))))
     _touch(param)
     return None
 
@@ -321,6 +321,15 @@ def _conv_geom_fwd(H, W, C, OH, OW, k, stride, pad):
 _BN_EPILOGUE_STATS = __import__("os").environ.get("STIL_BN_EPILOGUE_STATS", "1") != "0"
 
 
+_BN_DEFER = __import__("os").environ.get("STIL_BN_DEFER", "1") != "0"
+
+
+def can_defer_bn(Cout: int) -> bool:
+    """May a conv+BN+ReLU layer with Cout channels leave its BatchNorm + ReLU to the consumer's operand staging?
+    (the consumer's GEMM needs Cin % 16 == 0; STIL_BN_DEFER=0 materialises every z as before)"""
+    return _BN_DEFER and _BN_EPILOGUE_STATS and Cout % 16 == 0 and Cout <= 2048
+
+
 class ConvBnActFn(torch.autograd.Function):
     """z = relu?( BN_train(conv(x, w)) + residual? ) on NHWC activations.
 
@@ -329,12 +338,19 @@ class ConvBnActFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, rmean, rvar, nbt, resid, k, stride, pad, relu, stem, passthrough=False):
+    def forward(ctx, x, w, gamma, beta, rmean, rvar, nbt, resid, k, stride, pad, relu, stem, passthrough=False, defer=False, xstats=None):
         """passthrough: also return x itself as a second output.  A residual block routes its identity branch through
         that alias, so the branch's gradient arrives HERE and is added inside the input-gradient GEMM's epilogue
-        instead of by a separate accumulation kernel of the autograd engine."""
+        instead of by a separate accumulation kernel of the autograd engine.
+        defer (inner layers of a residual block: ReLU, no residual): BatchNorm + ReLU are NOT applied here -- the node
+        returns the raw conv output y and, as a last extra output, its statistics block [4, Cout]; the consumer conv
+        passes them back as `xstats` and forms z = relu((y - mean) * a + beta) while it stages its operand (forward
+        GEMM and weight-gradient GEMM: stil_gemm_nt a_bn / stil_wgrad_tn x_bn), so z is never written or read.  The
+        gradient this node receives is still the one w.r.t. z: its backward is unchanged (the ReLU mask is recomputed
+        from y and the statistics, bn_train_bwd relu = 2)."""
         _chk(x, w, gamma, beta, resid)
         ctx.set_materialize_grads(False)
+        assert not defer or (relu and resid is None), "only conv+BN+ReLU layers without a residual can defer their BatchNorm"
         Cout = w.shape[0]
         dev = x.device
         fused = _BN_EPILOGUE_STATS and Cout % 4 == 0
@@ -361,9 +377,11 @@ class ConvBnActFn(torch.autograd.Function):
                 wf = torch.empty((Cout, k * k * Cin), dtype=torch.float32, device=dev)
                 lib().conv_weight_layout(_p(w), _p(wf), None, Cout, Cin, k, k, _stream())
             geom = _conv_geom_fwd(H, W_, Cin, OH, OW, k, stride, pad)
-            y = gemm_nt(x, wf, M, Cout, k * k * Cin, geom=geom, colstats=ts)
+            y = gemm_nt(x, wf, M, Cout, k * k * Cin, geom=geom, colstats=ts, a_bn=xstats)
         stats = torch.empty((4, Cout), dtype=torch.float32, device=dev)
-        z = torch.empty((M, Cout), dtype=torch.float32, device=dev)
+        assert fused or not defer, "deferred BatchNorm needs the epilogue statistics (can_defer_bn)"
+        # deferred: no z.  Under parity tracing the tests still want this layer's ReLU decisions: z is materialised for them
+        z = None if (defer and _trace is None) else torch.empty((M, Cout), dtype=torch.float32, device=dev)
         if fused:
             nb = lib().bn_tiles_workspace_bytes(M, Cout, tile_rows)
             ws = _ws.get(nb, dev)
@@ -376,15 +394,22 @@ class ConvBnActFn(torch.autograd.Function):
                                1 if relu else 0, 1e-5, 0.1, _p(ws), nb, _stream())
         if _trace is not None and relu:
             _trace["relu"][id(gamma)] = z.view(Nb, OH, OW, Cout)
-        ctx.save_for_backward(x, w, gamma, beta, y, z, stats)
+        ctx.save_for_backward(x, w, gamma, beta, y, None if defer else z, stats, xstats)
         ctx.cfg = (k, stride, pad, relu, stem is not None, resid is not None, geom, (Nb, OH, OW), stem)
+        ctx.has_alias = bool(passthrough)
+        out = (y if defer else z).view(Nb, OH, OW, Cout)
+        if defer:
+            ctx.mark_non_differentiable(stats)
+            return (out, x, stats) if passthrough else (out, stats)
         if passthrough:
-            return z.view(Nb, OH, OW, Cout), x
-        return z.view(Nb, OH, OW, Cout)
+            return out, x
+        return out
 
     @staticmethod
-    def backward(ctx, gz, gx_alias=None):
-        x, w, gamma, beta, y, z, stats = ctx.saved_tensors
+    def backward(ctx, gz, *more):
+        x, w, gamma, beta, y, z, stats, xstats = ctx.saved_tensors
+        # outputs: (out[, x alias][, stats]) -- the alias gradient is the only other one that can carry a value
+        gx_alias = more[0] if (len(more) and ctx.has_alias) else None
         k, stride, pad, relu, is_stem, has_res, geom, (Nb, OH, OW), stem = ctx.cfg
         dev = x.device
         Cout = w.shape[0]
@@ -432,9 +457,9 @@ class ConvBnActFn(torch.autograd.Function):
             elif gx_alias is not None:
                 dx = gx_alias
             gw = geom[:9]
-            dw = wgrad_param(w, dy, x, M, Cout, k * k * Cin, geom=gw)
+            dw = wgrad_param(w, dy, x, M, Cout, k * k * Cin, geom=gw, x_bn=xstats)
         return (dx, dw, (None if gslot is not None else dgamma), (None if bslot is not None else dbeta), None, None, None,
-                dres, None, None, None, None, None, None)
+                dres, None, None, None, None, None, None, None, None)
 
 
 def strided_dgrad(dy, w, Nb, H, W_, Cin, OH, OW, Cout, k, stride, pad):

@@ -149,6 +149,58 @@ def test_conv_bn_act_train_and_eval(ops, Cin, Cout, k, stride, pad, H, relu, res
     close(nchw(ze), ye, name="eval")
 
 
+@pytest.mark.parametrize("C1,C2,k2,stride2,H,res2", [(64, 64, 3, 1, 9, False), (64, 128, 3, 2, 10, False), (128, 64, 1, 1, 6, True), (64, 64, 3, 1, 7, True),
+                                                    (512, 128, 1, 1, 5, False)])
+def test_deferred_batchnorm_is_the_materialised_path_bit_for_bit(ops, C1, C2, k2, stride2, H, res2):
+    """models/resnets.py:112-132 inner layers: conv1+bn1+relu -> conv2+bn2(+residual)+relu.  With `defer` the first node
+    returns its RAW conv output and its statistics; the second applies bn1 + relu while it stages its operand (forward GEMM
+    a_bn, weight-gradient GEMM x_bn) and z1 never exists.  Same arithmetic on the same values: outputs, running buffers
+    and every gradient must equal the materialised chain exactly; and the chain still matches ATen."""
+    g = torch.Generator().manual_seed(C1 + k2)
+    Nb, Cin = 3, 32
+    x = torch.randn(Nb, Cin, H, H, generator=g)
+    w1 = torch.randn(C1, Cin, 1, 1, generator=g) * 0.2
+    w2 = torch.randn(C2, C1, k2, k2, generator=g) * 0.1
+    g1, b1 = 0.5 + torch.rand(C1, generator=g), 0.3 * torch.randn(C1, generator=g)
+    g2, b2 = 0.5 + torch.rand(C2, generator=g), 0.1 * torch.randn(C2, generator=g)
+    pad2 = k2 // 2
+    OH = (H + 2 * pad2 - k2) // stride2 + 1
+    r = torch.randn(Nb, C2, OH, OH, generator=g) if res2 else None
+    gy = torch.randn(Nb, C2, OH, OH, generator=g)
+
+    def run(defer):
+        leaves = [nhwc(x).requires_grad_()] + [dev(t).requires_grad_() for t in (w1, g1, b1, w2, g2, b2)]
+        xd, w1d, g1d, b1d, w2d, g2d, b2d = leaves
+        bufs = [torch.zeros(C1, device="cuda"), torch.ones(C1, device="cuda"), torch.zeros((), dtype=torch.long, device="cuda"),
+                torch.zeros(C2, device="cuda"), torch.ones(C2, device="cuda"), torch.zeros((), dtype=torch.long, device="cuda")]
+        rd = nhwc(r).view(-1, C2).requires_grad_() if res2 else None
+        if defer:
+            h, st = ops.ConvBnActFn.apply(xd, w1d, g1d, b1d, bufs[0], bufs[1], bufs[2], None, 1, 1, 0, True, None, False, True)
+            assert st.shape == (4, C1) and not st.requires_grad
+        else:
+            h, st = ops.ConvBnActFn.apply(xd, w1d, g1d, b1d, bufs[0], bufs[1], bufs[2], None, 1, 1, 0, True, None), None
+        z = ops.ConvBnActFn.apply(h, w2d, g2d, b2d, bufs[3], bufs[4], bufs[5], rd, k2, stride2, pad2, True, None, False, False, st)
+        z.backward(nhwc(gy))
+        torch.cuda.synchronize()
+        return [z.detach()] + [t.grad for t in leaves] + ([rd.grad] if res2 else []) + bufs
+
+    a, b = run(False), run(True)
+    names = ["z", "dx", "dw1", "dgamma1", "dbeta1", "dw2", "dgamma2", "dbeta2"] + (["dres"] if res2 else []) + ["rm1", "rv1", "nbt1", "rm2", "rv2", "nbt2"]
+    for n, u, v in zip(names, a, b):
+        assert torch.equal(u, v), f"{n}: deferred BatchNorm differs from the materialised path (max |d| = {float((u - v).abs().max()):.3e})"
+    # ... and the chain is the reference's arithmetic (ATen-CPU fp32)
+    xr, w1r, g1r, b1r, w2r, g2r, b2r = [t.clone().requires_grad_() for t in (x, w1, g1, b1, w2, g2, b2)]
+    hr = F.relu(F.batch_norm(F.conv2d(xr, w1r), torch.zeros(C1), torch.ones(C1), g1r, b1r, training=True, eps=1e-5))
+    yr = F.batch_norm(F.conv2d(hr, w2r, stride=stride2, padding=pad2), torch.zeros(C2), torch.ones(C2), g2r, b2r, training=True, eps=1e-5)
+    yr = F.relu(yr + r if res2 else yr)
+    yr.backward(gy)
+    close(nchw(b[0]), yr, name="z vs ATen")
+    close(nchw(b[1]), xr.grad, tol=5e-5, name="dx vs ATen")
+    close(b[2], w1r.grad, tol=5e-5, name="dw1 vs ATen")
+    close(b[5], w2r.grad, tol=5e-5, name="dw2 vs ATen")
+    close(b[3], g1r.grad, tol=5e-5, name="dgamma1 vs ATen")
+
+
 def test_stem_and_maxpool(ops):
     g = torch.Generator().manual_seed(5)
     Nb, H = 3, 40
