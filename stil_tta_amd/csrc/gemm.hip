@@ -191,7 +191,7 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNTArgs& p, f32x16 (&a
 // zero padding of a conv gather stays zero).  Same arithmetic as bn_apply_kernel, so the products are those of the
 // materialised path bit for bit.
 template <int TM, int TN, int BK, bool VEC, bool ACC2 = false, bool PLAIN = false, bool BNA = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BK == 16 && VEC) ? (TM * TN == 1 ? 6 : ((TM * TN == 2 && ACC2 && (PLAIN || TN == 2)) ? 4 : 1)) : 1)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BK == 16 && VEC) ? (TM * TN == 1 ? ((BNA && ACC2 && !PLAIN) ? 5 : 6) : ((TM * TN == 2 && ACC2 && (PLAIN || TN == 2)) ? 4 : 1)) : 1)))
 void gemm_nt_kernel(GemmNTArgs p) {
   constexpr int BM = 64 * TM, BN = 64 * TN, LS = BK + 4;   // LS = 20 / 36: conflict-free ds_read_b128 (i*LS mod 64 distinct)
   constexpr int KQ = BK / 4, RP = 256 / KQ;                 // float4 per tile row, tile rows per load pass
