@@ -13,7 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(_ROOT, "include", "stil_hip.h")
-LIB_PATH = os.path.join(_HERE, "lib", "libstil_hip.so")
+LIB_PATH = os.environ.get("STIL_LIB_PATH") or os.path.join(_HERE, "lib", "libstil_hip.so")  # STIL_LIB_PATH: A/B builds of the same sources (tests/tools)
 CSRC = os.path.join(_HERE, "csrc")
 
 _CTYPES = {
