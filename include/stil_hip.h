@@ -56,6 +56,8 @@ int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, 
  *   bk32     1 = 32-deep LDS k-tiles instead of 16;
  *   acc2     two-level accumulation (partial chains of 64 products added to a master accumulator, ~ATen-CPU's
  *            rounding noise for long reductions): 0 = for K >= 512, 1 = never, 2 = always.
+ *   + 10000  scalar epilogue (one dword per lane) instead of the 16-byte one 64x64 tiles use when N, ldc, ldr % 4 == 0 and
+ *            every output-side pointer is 16-byte aligned (accumulators transposed through LDS; identical results).
  * rows per output tile / tile variant stil_gemm_nt uses for an [M,N] output under `tune` (colstats granularity, bench bookkeeping) */
 int stil_gemm_nt_tile_rows(int M, int N, int tune);
 int stil_gemm_nt_variant(int M, int N, int tune);

@@ -52,6 +52,7 @@ struct GemmNTArgs {
   // of a bottleneck reads the raw conv output y of the layer before it; z = relu((y - mean) * a + beta) is never
   // materialised): abn = that layer's statistics block [4][C] = mean, rstd, a = gamma * rstd, beta (bn.hip)
   const float* abn;
+  int wide;   // 1: 16-byte epilogue (64x64 tiles; N, ldc, ldr % 4 == 0 and C / resid / pre / per-column vectors 16-byte aligned)
 };
 
 __device__ __forceinline__ float4 ld4_guard(const float* p, int nvalid, int vec) {
@@ -138,6 +139,56 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNTArgs& p, f32x16 (&a
           p.colstats[((long)tm * 2 + 1) * p.N + col] = red[cs] + red[BN + cs];
         }
       }
+    }
+  }
+
+  // Wide epilogue (64x64 tiles): the accumulators go through LDS once (the operand buffers are free by now) so that every
+  // lane handles FOUR consecutive columns of a row: residual loads, `pre` stores and output stores are 16 bytes per lane
+  // (a wave instruction covers 4 rows x 256 B) instead of one dword per lane (2 rows x 128 B) -- a quarter of the memory
+  // instructions for the same bytes.  The short-K products, whose time is their epilogue's traffic, are bound by the
+  // number of those instructions.  Same per-element arithmetic in the same order as the scalar path below: identical bits.
+  if constexpr (TM == 1 && TN == 1) {
+    if (p.wide) {
+      constexpr int TS = BN + 4;            // 68 floats: rows 16-byte aligned, ds_read_b128 rows conflict-free
+      float* T = red;                       // 64 x 68 floats = 17 KB <= the 20 KB of operand buffers
+      __syncthreads();                      // the statistics scratch (same LDS) is done with
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        T[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * TS + wn * 32 + li] = acc[0][0][r];
+      __syncthreads();
+      const int tid = threadIdx.x, cq = (tid & 15) * 4, col = tn * BN + cq;
+      if (col < p.N) {
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f), one4 = make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 bia = p.bias ? *reinterpret_cast<const float4*>(p.bias + col) : zero4;
+        const float4 sb = p.sub ? *reinterpret_cast<const float4*>(p.sub + col) : zero4;
+        const float4 sc = p.scale ? *reinterpret_cast<const float4*>(p.scale + col) : one4;
+        const float4 sh = p.shift ? *reinterpret_cast<const float4*>(p.shift + col) : zero4;
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+          const int rl = ps * 16 + (tid >> 4), row_m = tm * BM + rl;
+          if (row_m >= p.M) continue;
+          long row = row_m;
+          if (!PLAIN && p.os != 1) {
+            const int ohw = g.OH * g.OW;
+            const int n = row_m / ohw, rem = row_m - n * ohw;
+            const int oy = rem / g.OW, ox = rem - oy * g.OW;
+            row = ((long)n * p.oOH + oy * p.os + p.opy) * p.oOW + ox * p.os + p.opx;
+          }
+          float4 v = *reinterpret_cast<const float4*>(T + rl * TS + cq);
+          v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
+          v.x = (v.x - sb.x) * sc.x + sh.x + bia.x; v.y = (v.y - sb.y) * sc.y + sh.y + bia.y;
+          v.z = (v.z - sb.z) * sc.z + sh.z + bia.z; v.w = (v.w - sb.w) * sc.w + sh.w + bia.w;
+          if (p.resid) {
+            const float4 rr = *reinterpret_cast<const float4*>(p.resid + row * p.ldr + col);
+            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+          }
+          if (p.pre) *reinterpret_cast<float4*>(p.pre + row * p.ldc + col) = v;
+          if (p.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          else if (p.act == 2) { v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w); }
+          *reinterpret_cast<float4*>(p.C + row * p.ldc + col) = v;
+        }
+      }
+      return;
     }
   }
 
@@ -666,6 +717,7 @@ static int gemm_nt_attr() {
 //   acc2: 1 = single-chain accumulation, 2 = two-level accumulation, 0 = two-level for K >= 512
 // which tile variant stil_gemm_nt launches for an [M,N] output
 extern "C" int stil_gemm_nt_variant(int M, int N, int tune) {
+  tune %= 10000;   // + 10000 = scalar epilogue: no bearing on the tile
   const int forced = tune % 100;
   if (forced == 11 || forced == 21 || forced == 22 || forced == 12) return forced;
   // measured (tests/tools/gemm_bench.py, profiles/r02t-u): with 6 waves per SIMD the 64x64 tile is at least as fast as
@@ -682,6 +734,7 @@ extern "C" int stil_gemm_nt_tile_rows(int M, int N, int tune) { const int v = st
 // output map, i.e. A is a plain row-major matrix.  The launcher below calls the same function.
 extern "C" int stil_gemm_nt_config(const float* A, const float* W, int M, int N, int K, int lda, int ldb, int srcC, int KH, int KW,
                                    int plain, int a_bn, int tune) {
+  tune %= 10000;
   const int variant = stil_gemm_nt_variant(M, N, tune);
   const bool bk32 = (tune / 100) % 10 == 1 && (K % 32 == 0) && (KH * KW == 1 || srcC % 32 == 0);
   const bool acc2 = tune / 1000 == 2 || (tune / 1000 == 0 && K >= 512);
@@ -696,9 +749,11 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
                             int pad_x, int mode, int out_stride, int out_py, int out_px, int out_OH, int out_OW,
                             const float* bias, const float* sub, const float* scale,
                             const float* shift, const float* resid, int ldr, float* pre, int act, float alpha,
-                            float* colstats, const float* a_bn, int tune, void* stream) {
+                            float* colstats, const float* a_bn, int tune_arg, void* stream) {
+  const int tune = tune_arg % 10000;                 // + 10000: scalar (one dword per lane) epilogue, for A/B measurements and tests
+  const bool scalar_epilogue = tune_arg / 10000 == 1;
   STIL_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0, "stil_gemm_nt: null pointer or empty shape (M=%d N=%d K=%d)", M, N, K);
-  STIL_REQUIRE(tune >= 0 && tune < 3000 && (tune % 100 == 0 || tune % 100 == 11 || tune % 100 == 21 || tune % 100 == 22 || tune % 100 == 12) && (tune / 100) % 10 <= 1,
+  STIL_REQUIRE(tune_arg >= 0 && tune_arg < 20000 && tune < 3000 && (tune % 100 == 0 || tune % 100 == 11 || tune % 100 == 21 || tune % 100 == 22 || tune % 100 == 12) && (tune / 100) % 10 <= 1,
                "stil_gemm_nt: bad tune %d", tune);
   STIL_REQUIRE(KH * KW * srcC == K, "stil_gemm_nt: K=%d != KH*KW*C=%d", K, KH * KW * srcC);
   STIL_REQUIRE(M % (OH * OW) == 0, "stil_gemm_nt: M=%d not a multiple of OH*OW=%d", M, OH * OW);
@@ -710,6 +765,11 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   p.alpha = alpha;
   p.colstats = colstats;
   p.abn = a_bn;
+  {
+    auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q % 16) == 0; };
+    p.wide = (N % 4 == 0) && (ldc % 4 == 0) && (!resid || ldr % 4 == 0) && al16(C) && al16(resid) && al16(pre) && al16(bias) && al16(sub) &&
+             al16(scale) && al16(shift) && !scalar_epilogue ? 1 : 0;
+  }
   STIL_REQUIRE(!colstats || (p.os == 1 && !bias && !sub && !scale && !shift && !resid && act == 0),
                "stil_gemm_nt: colstats describes the raw product (no bias / affine / residual / activation / output map)");
   p.vecA = is_vec(A, lda) && (srcC % 4 == 0);

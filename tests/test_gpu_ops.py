@@ -53,6 +53,37 @@ def test_gemm_nt_plain(ops, M, N, K, act):
     close(pre, ref_pre, name="pre")
 
 
+def test_gemm_nt_wide_epilogue_is_the_scalar_one_bit_for_bit(ops):
+    """64x64 tiles stage their accumulators through LDS so that residual loads, `pre` stores and output stores are 16 bytes
+    per lane (csrc/gemm.hip); `tune + 10000` keeps the one-dword-per-lane epilogue.  Same arithmetic per element: the two
+    must agree exactly, with every epilogue feature on (alpha, eval-BN affine, bias, residual, pre, ReLU / GELU, conv gather,
+    ragged M / N edges, per-tile statistics)."""
+    g = torch.Generator().manual_seed(11)
+    for M, N, K, act in [(4100, 64, 64, 1), (5000, 200, 96, 2), (130, 260, 512, 0), (64 * 37 + 5, 128, 1024, 1)]:
+        A, W = dev(torch.randn(M, K, generator=g)), dev(torch.randn(N, K, generator=g))
+        bias, sub, scale, shift = (dev(torch.randn(N, generator=g)) for _ in range(4))
+        R = dev(torch.randn(M, N, generator=g))
+        outs = []
+        for tune in (0, 10000):
+            ops.TUNE["gemm"] = tune
+            pre = torch.empty(M, N, device="cuda")
+            ts = torch.empty(2 * ((M + 63) // 64), N, device="cuda")
+            o = ops.gemm_nt(A, W, M, N, K, bias=bias, sub=sub, scale=scale, shift=shift, resid=R, pre=pre, act=act, alpha=0.7)
+            raw = ops.gemm_nt(A, W, M, N, K, colstats=ts)
+            outs.append((o.clone(), pre.clone(), raw.clone(), ts.clone()))
+        ops.TUNE["gemm"] = 0
+        for u, v, n in zip(outs[0], outs[1], ("out", "pre", "raw", "tile statistics")):
+            assert torch.equal(u, v), f"{n} differs between the 16-byte and the scalar epilogue at {(M, N, K)}"
+    # conv gather + strided output map (phase-decomposed dgrad)
+    x = dev(torch.randn(3, 9, 9, 32, generator=g)); w = dev(torch.randn(64, 9 * 32, generator=g))
+    outs = []
+    for tune in (0, 10000):
+        ops.TUNE["gemm"] = tune
+        outs.append(ops.gemm_nt(x, w, 3 * 81, 64, 9 * 32, geom=(9, 9, 32, 9, 9, 3, 3, 1, 1, 0)).clone())
+    ops.TUNE["gemm"] = 0
+    assert torch.equal(outs[0], outs[1])
+
+
 CONVS = [  # Cin, Cout, k, stride, pad, H
     (64, 64, 1, 1, 0, 14), (64, 128, 1, 2, 0, 14), (32, 64, 3, 1, 1, 9), (64, 48, 3, 2, 1, 14), (16, 32, 3, 2, 1, 7),
     (128, 256, 3, 1, 1, 4),
