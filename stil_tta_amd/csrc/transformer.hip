@@ -503,6 +503,35 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
   }
 }
 
+// four elements per thread (n % 4 == 0, 16-byte aligned pointers): one dwordx4 per operand instead of four dwords -- these
+// passes are bound by the number of memory instructions long before they are bound by bytes
+__global__ void act_bwd4_kernel(const float4* __restrict__ dy, const float4* __restrict__ ref, float4* __restrict__ dx,
+                                long n4, int kind) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 r = ref[i], g = dy[i];
+    float4 o;
+    if (kind == 1) {
+      o.x = r.x > 0.f ? g.x : 0.f; o.y = r.y > 0.f ? g.y : 0.f; o.z = r.z > 0.f ? g.z : 0.f; o.w = r.w > 0.f ? g.w : 0.f;
+    } else {
+      o.x = g.x * gelu_grad_f(r.x); o.y = g.y * gelu_grad_f(r.y); o.z = g.z * gelu_grad_f(r.z); o.w = g.w * gelu_grad_f(r.w);
+    }
+    dx[i] = o;
+  }
+}
+__global__ void drop_add4_kernel(const float4* __restrict__ x, const float4* __restrict__ resid,
+                                 const uchar4* __restrict__ emask, const unsigned char* __restrict__ rmask,
+                                 float4* __restrict__ out, long n4, int rowlen4, float scale) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 k = make_float4(scale, scale, scale, scale);
+    if (emask) { const uchar4 e = emask[i]; if (!e.x) k.x = 0.f; if (!e.y) k.y = 0.f; if (!e.z) k.z = 0.f; if (!e.w) k.w = 0.f; }
+    if (rmask && !rmask[i / rowlen4]) k = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 a = x[i];
+    float4 v = make_float4(a.x * k.x, a.y * k.y, a.z * k.z, a.w * k.w);
+    if (resid) { const float4 r = resid[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+    out[i] = v;
+  }
+}
+
 // out = (resid ? resid : 0) + x * emask[i] * rmask[i / rowlen] * scale
 __global__ void drop_add_kernel(const float* __restrict__ x, const float* __restrict__ resid,
                                 const unsigned char* __restrict__ emask, const unsigned char* __restrict__ rmask,
@@ -800,7 +829,11 @@ extern "C" int stil_attention_bwd(const float* dout, const float* qkv, const flo
 
 extern "C" int stil_act_bwd(const float* dy, const float* ref, float* dx, long n, int kind, void* stream) {
   STIL_REQUIRE(dy && ref && dx && (kind == 1 || kind == 2), "stil_act_bwd: bad arguments");
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, ref, dx, n, kind);
+  if (n % 4 == 0 && (((uintptr_t)dy | (uintptr_t)ref | (uintptr_t)dx) % 16) == 0)
+    hipLaunchKernelGGL(act_bwd4_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float4*)dy, (const float4*)ref,
+                       (float4*)dx, n / 4, kind);
+  else
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, ref, dx, n, kind);
   STIL_LAUNCH_CHECK();
   return STIL_OK;
 }
@@ -808,8 +841,12 @@ extern "C" int stil_act_bwd(const float* dy, const float* ref, float* dx, long n
 extern "C" int stil_drop_add(const float* x, const float* resid, const unsigned char* emask, const unsigned char* rmask,
                              float* out, long n, int rowlen, float scale, void* stream) {
   STIL_REQUIRE(x && out && rowlen > 0, "stil_drop_add: bad arguments");
-  hipLaunchKernelGGL(drop_add_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, resid, emask, rmask, out,
-                     n, rowlen, scale);
+  if (n % 4 == 0 && rowlen % 4 == 0 && (((uintptr_t)x | (uintptr_t)resid | (uintptr_t)out) % 16) == 0 && ((uintptr_t)emask % 4) == 0)
+    hipLaunchKernelGGL(drop_add4_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (const float4*)resid,
+                       (const uchar4*)emask, rmask, (float4*)out, n / 4, rowlen / 4, scale);
+  else
+    hipLaunchKernelGGL(drop_add_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, resid, emask, rmask, out,
+                       n, rowlen, scale);
   STIL_LAUNCH_CHECK();
   return STIL_OK;
 }
