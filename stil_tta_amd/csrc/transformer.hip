@@ -5,30 +5,56 @@
 #include "common.h"
 
 // ---------------------------------------------------------------- LayerNorm (one wave per row)
+// VEC4 (D % 4 == 0, 16-byte aligned rows): every lane owns quads of consecutive columns -- one dwordx4 per operand
+// instead of four dwords (these passes are bound by the number of memory instructions, not by bytes)
+template <bool VEC4>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ y,
                                                              float* __restrict__ mean_rstd, int rows, int D, float eps) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   const float* xr = x + (long)row * D;
+  float* yr = y + (long)row * D;
+  if constexpr (VEC4) {
+    float s = 0.f;
+    for (int i = lane * 4; i < D; i += 256) { const float4 v = *reinterpret_cast<const float4*>(xr + i); s += (v.x + v.y) + (v.z + v.w); }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+    for (int i = lane * 4; i < D; i += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(xr + i);
+      const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+    const float rstd = 1.f / sqrtf(wave_sum(q) / (float)D + eps);
+    for (int i = lane * 4; i < D; i += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(xr + i), gm = *reinterpret_cast<const float4*>(gamma + i),
+                   bt = *reinterpret_cast<const float4*>(beta + i);
+      float4 o;
+      o.x = (v.x - mean) * rstd * gm.x + bt.x; o.y = (v.y - mean) * rstd * gm.y + bt.y;
+      o.z = (v.z - mean) * rstd * gm.z + bt.z; o.w = (v.w - mean) * rstd * gm.w + bt.w;
+      *reinterpret_cast<float4*>(yr + i) = o;
+    }
+    if (lane == 0) { mean_rstd[2 * row] = mean; mean_rstd[2 * row + 1] = rstd; }
+    return;
+  }
   float s = 0.f;
   for (int i = lane; i < D; i += 64) s += xr[i];
   const float mean = wave_sum(s) / (float)D;
   float v = 0.f;
   for (int i = lane; i < D; i += 64) { float d = xr[i] - mean; v += d * d; }
   const float rstd = 1.f / sqrtf(wave_sum(v) / (float)D + eps);
-  float* yr = y + (long)row * D;
   for (int i = lane; i < D; i += 64) yr[i] = (xr[i] - mean) * rstd * gamma[i] + beta[i];
   if (lane == 0) { mean_rstd[2 * row] = mean; mean_rstd[2 * row + 1] = rstd; }
 }
 
 // dx per row; per-block column partials of dgamma (g*xhat) and dbeta (g): part[blk][2][D]
+template <bool VEC4>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ mean_rstd, float* __restrict__ dx,
                                                              float* __restrict__ part, int rows, int D,
                                                              int rows_per_block) {
-  extern __shared__ float sh[];  // [4][2][D]
+  extern __shared__ __attribute__((aligned(16))) float sh[];  // [4][2][D]
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
   float* my = sh + (long)w * 2 * D;
@@ -36,8 +62,32 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   for (int row = r0 + w; row < r1; row += 4) {
     const float* xr = x + (long)row * D;
     const float* gr = g + (long)row * D;
+    float* dr = dx + (long)row * D;
     const float mean = mean_rstd[2 * row], rstd = mean_rstd[2 * row + 1];
     float a = 0.f, b = 0.f;
+    if constexpr (VEC4) {   // lane-private column quads: no race on `my`
+      for (int i = lane * 4; i < D; i += 256) {
+        const float4 gv = *reinterpret_cast<const float4*>(gr + i), xv = *reinterpret_cast<const float4*>(xr + i),
+                     gm = *reinterpret_cast<const float4*>(gamma + i);
+        const float h0 = (xv.x - mean) * rstd, h1 = (xv.y - mean) * rstd, h2 = (xv.z - mean) * rstd, h3 = (xv.w - mean) * rstd;
+        const float g0 = gv.x * gm.x, g1 = gv.y * gm.y, g2 = gv.z * gm.z, g3 = gv.w * gm.w;
+        a += (g0 + g1) + (g2 + g3); b += (g0 * h0 + g1 * h1) + (g2 * h2 + g3 * h3);
+        float4 m0 = *reinterpret_cast<float4*>(my + i), m1 = *reinterpret_cast<float4*>(my + D + i);
+        m0.x += gv.x * h0; m0.y += gv.y * h1; m0.z += gv.z * h2; m0.w += gv.w * h3;
+        m1.x += gv.x; m1.y += gv.y; m1.z += gv.z; m1.w += gv.w;
+        *reinterpret_cast<float4*>(my + i) = m0; *reinterpret_cast<float4*>(my + D + i) = m1;
+      }
+      a = wave_sum(a) / (float)D; b = wave_sum(b) / (float)D;
+      for (int i = lane * 4; i < D; i += 256) {
+        const float4 gv = *reinterpret_cast<const float4*>(gr + i), xv = *reinterpret_cast<const float4*>(xr + i),
+                     gm = *reinterpret_cast<const float4*>(gamma + i);
+        float4 o;
+        o.x = rstd * (gv.x * gm.x - a - (xv.x - mean) * rstd * b); o.y = rstd * (gv.y * gm.y - a - (xv.y - mean) * rstd * b);
+        o.z = rstd * (gv.z * gm.z - a - (xv.z - mean) * rstd * b); o.w = rstd * (gv.w * gm.w - a - (xv.w - mean) * rstd * b);
+        *reinterpret_cast<float4*>(dr + i) = o;
+      }
+      continue;
+    }
     for (int i = lane; i < D; i += 64) {
       float gg = gr[i] * gamma[i], xh = (xr[i] - mean) * rstd;
       a += gg; b += gg * xh;
@@ -45,7 +95,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       my[D + i] += gr[i];
     }
     a = wave_sum(a) / (float)D; b = wave_sum(b) / (float)D;
-    float* dr = dx + (long)row * D;
     for (int i = lane; i < D; i += 64) {
       float xh = (xr[i] - mean) * rstd;
       dr[i] = rstd * (gr[i] * gamma[i] - a - xh * b);
@@ -715,8 +764,11 @@ static inline int ew_grid(long n) { long g = (n + 255) / 256; return (int)(g < 1
 extern "C" int stil_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean_rstd,
                                   int rows, int D, float eps, void* stream) {
   STIL_REQUIRE(x && gamma && beta && y && mean_rstd && rows > 0 && D > 0, "stil_layernorm_fwd: bad arguments");
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
-                     mean_rstd, rows, D, eps);
+  const bool v4 = D % 4 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) % 16) == 0;
+  if (v4) hipLaunchKernelGGL(layernorm_fwd_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
+                             mean_rstd, rows, D, eps);
+  else hipLaunchKernelGGL(layernorm_fwd_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
+                          mean_rstd, rows, D, eps);
   STIL_LAUNCH_CHECK();
   return STIL_OK;
 }
@@ -731,7 +783,8 @@ extern "C" int stil_layernorm_bwd(const float* g, const float* x, const float* g
   STIL_REQUIRE(D <= 4096, "stil_layernorm_bwd: D=%d > 4096", D);
   static bool attr_set = false;
   if (!attr_set) {  // 8*D floats of LDS: > 64 KiB for D > 2048 (SAINT's row LayerNorm has D = 32 * nfeats = 2080)
-    hipError_t e = hipFuncSetAttribute((const void*)layernorm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)layernorm_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)layernorm_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
     if (e != hipSuccess) { stil_set_error("layernorm_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return STIL_EHIP; }
     attr_set = true;
   }
@@ -739,8 +792,11 @@ extern "C" int stil_layernorm_bwd(const float* g, const float* x, const float* g
   STIL_REQUIRE(workspace_bytes >= (size_t)nb * 2 * D * sizeof(float), "stil_layernorm_bwd: workspace too small");
   int rpb = cdiv(rows, nb);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), (size_t)8 * D * sizeof(float), s, g, x, gamma, mean_rstd,
-                     dx, workspace, rows, D, rpb);
+  const bool v4 = D % 4 == 0 && (((uintptr_t)g | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dx) % 16) == 0;
+  if (v4) hipLaunchKernelGGL(layernorm_bwd_kernel<true>, dim3(nb), dim3(256), (size_t)8 * D * sizeof(float), s, g, x, gamma, mean_rstd,
+                             dx, workspace, rows, D, rpb);
+  else hipLaunchKernelGGL(layernorm_bwd_kernel<false>, dim3(nb), dim3(256), (size_t)8 * D * sizeof(float), s, g, x, gamma, mean_rstd,
+                          dx, workspace, rows, D, rpb);
   STIL_LAUNCH_CHECK();
   hipLaunchKernelGGL(ln_final_kernel, dim3(cdiv(2 * D, 32)), dim3(256), 0, s, workspace, nb, D, dgamma, dbeta, accumulate);
   STIL_LAUNCH_CHECK();
