@@ -53,7 +53,7 @@ int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, 
  *   residual block never materialise z (models/resnets.py:112-132: bn1/relu, bn2/relu fused into conv2 / conv3).
  * `tune` (0 = automatic; otherwise for A/B measurements) = variant + 100 * bk32 + 1000 * acc2:
  *   variant  block tile: 22 = 128x128, 21 = 128x64, 12 = 64x128, 11 = 64x64 (0: automatic = 64x64, the fastest on the shapes of the step);
- *   bk32     1 = 32-deep LDS k-tiles instead of 16;
+ *   bk32     32-deep LDS k-tiles instead of 16: 0 = automatic (plain products with K >= 256), 1 = wherever possible, 2 = never;
  *   acc2     two-level accumulation (partial chains of 64 products added to a master accumulator, ~ATen-CPU's
  *            rounding noise for long reductions): 0 = for K >= 512, 1 = never, 2 = always.
  *   + 10000  scalar epilogue (one dword per lane) instead of the 16-byte one 64x64 tiles use when N, ldc, ldr % 4 == 0 and

@@ -766,7 +766,11 @@ extern "C" int stil_gemm_nt_config(const float* A, const float* W, int M, int N,
                                    int plain, int a_bn, int tune) {
   tune %= 10000;
   const int variant = stil_gemm_nt_variant(M, N, tune);
-  const bool bk32 = (tune / 100) % 10 == 1 && (K % 32 == 0) && (KH * KW == 1 || srcC % 32 == 0);
+  // 32-deep k-tiles: every staged row is one whole 128-byte line (16-deep tiles take half a line per k-tile and count on
+  // L1 for the other half); with the 16-byte epilogue they win on the plain products with K >= 256 (+3..10 %,
+  // profiles/r03_experiments.txt) although only 4 workgroups fit a CU, and lose on the conv gathers and the short ones.
+  const int bkd = (tune / 100) % 10;   // 0 automatic, 1 on, 2 off
+  const bool bk32 = (bkd == 1 || (bkd == 0 && plain && KH * KW == 1 && K >= 256 && !a_bn)) && (K % 32 == 0) && (KH * KW == 1 || srcC % 32 == 0);
   const bool acc2 = tune / 1000 == 2 || (tune / 1000 == 0 && K >= 512);
   const bool vec = is_vec(A, lda) && (srcC % 4 == 0) && is_vec(W, ldb) && (K % 4 == 0);  // every 16-byte load aligned and entirely in or out
   if (a_bn)   // operand-staging BatchNorm: 64x64 tiles, BK = 16 (see stil_gemm_nt)
@@ -783,7 +787,7 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   const int tune = tune_arg % 10000;                 // + 10000: scalar (one dword per lane) epilogue, for A/B measurements and tests
   const bool scalar_epilogue = tune_arg / 10000 == 1;
   STIL_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0, "stil_gemm_nt: null pointer or empty shape (M=%d N=%d K=%d)", M, N, K);
-  STIL_REQUIRE(tune_arg >= 0 && tune_arg < 20000 && tune < 3000 && (tune % 100 == 0 || tune % 100 == 11 || tune % 100 == 21 || tune % 100 == 22 || tune % 100 == 12) && (tune / 100) % 10 <= 1,
+  STIL_REQUIRE(tune_arg >= 0 && tune_arg < 20000 && tune < 3000 && (tune % 100 == 0 || tune % 100 == 11 || tune % 100 == 21 || tune % 100 == 22 || tune % 100 == 12) && (tune / 100) % 10 <= 2,
                "stil_gemm_nt: bad tune %d", tune);
   STIL_REQUIRE(KH * KW * srcC == K, "stil_gemm_nt: K=%d != KH*KW*C=%d", K, KH * KW * srcC);
   STIL_REQUIRE(M % (OH * OW) == 0, "stil_gemm_nt: M=%d not a multiple of OH*OW=%d", M, OH * OW);

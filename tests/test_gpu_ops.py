@@ -74,6 +74,15 @@ def test_gemm_nt_wide_epilogue_is_the_scalar_one_bit_for_bit(ops):
         ops.TUNE["gemm"] = 0
         for u, v, n in zip(outs[0], outs[1], ("out", "pre", "raw", "tile statistics")):
             assert torch.equal(u, v), f"{n} differs between the 16-byte and the scalar epilogue at {(M, N, K)}"
+    # 32-deep k-tiles (automatic for plain products with K >= 256) against 16-deep ones: same k order, same two-level sums
+    for M, N, K in [(300, 128, 256), (4100, 64, 1024), (130, 260, 2048)]:
+        A, W = dev(torch.randn(M, K, generator=g)), dev(torch.randn(N, K, generator=g))
+        outs = []
+        for tune in (100, 200):
+            ops.TUNE["gemm"] = tune
+            outs.append(ops.gemm_nt(A, W, M, N, K).clone())
+        ops.TUNE["gemm"] = 0
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], ops.gemm_nt(A, W, M, N, K)), (M, N, K)
     # conv gather + strided output map (phase-decomposed dgrad)
     x = dev(torch.randn(3, 9, 9, 32, generator=g)); w = dev(torch.randn(64, 9 * 32, generator=g))
     outs = []

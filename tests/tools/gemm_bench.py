@@ -37,7 +37,7 @@ NT += [(50176, 256, 1024, 1, 1, 0, 14), (12544, 512, 2048, 1, 1, 0, 7), (12544, 
 def tune(v):
     return lambda: ops.TUNE.__setitem__("gemm", v)
 # tune = variant + 100 * bk32 + 1000 * acc2 (include/stil_hip.h): auto / single-chain accumulation / per tile variant
-variants = [("auto", tune(0)), ("scalar-epi", tune(10000))]
+variants = [("auto", tune(0)), ("bk32", tune(100))]
 res = {}
 for r in range(2):  # interleaved rounds
     for name, setter in variants:
