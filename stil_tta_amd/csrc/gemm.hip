@@ -241,16 +241,19 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNTArgs& p, f32x16 (&a
 // global load and the LDS store (per-channel mean / a / beta from a 3 x C table staged in LDS once per workgroup; the
 // zero padding of a conv gather stays zero).  Same arithmetic as bn_apply_kernel, so the products are those of the
 // materialised path bit for bit.
-template <int TM, int TN, int BK, bool VEC, bool ACC2 = false, bool PLAIN = false, bool BNA = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((BK == 16 && VEC) ? (TM * TN == 1 ? ((BNA && ACC2 && !PLAIN) ? 5 : 6) : ((TM * TN == 2 && ACC2 && (PLAIN || TN == 2)) ? 4 : 1)) : 1)))
+// NB: number of LDS operand buffers.  2 = the next k-tile is stored while the current one is read (one barrier per k-tile);
+// 1 = one buffer, two barriers per k-tile, half the LDS: a 32-deep tile then costs what two 16-deep buffers cost and as
+// many workgroups fit a CU (the barriers are free: other workgroups' MFMAs fill them).
+template <int TM, int TN, int BK, bool VEC, bool ACC2 = false, bool PLAIN = false, bool BNA = false, int NB = 2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(((BK == 16 || NB == 1) && VEC) ? (TM * TN == 1 ? ((NB == 1 && ACC2) ? 4 : ((BNA && ACC2 && !PLAIN) ? 5 : 6)) : ((TM * TN == 2 && ACC2 && (PLAIN || TN == 2)) ? 4 : 1)) : 1)))
 void gemm_nt_kernel(GemmNTArgs p) {
   constexpr int BM = 64 * TM, BN = 64 * TN, LS = BK + 4;   // LS = 20 / 36: conflict-free ds_read_b128 (i*LS mod 64 distinct)
   constexpr int KQ = BK / 4, RP = 256 / KQ;                 // float4 per tile row, tile rows per load pass
   constexpr int RA = BM / RP, RB = BN / RP;
   extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 * (BM + BN) * LS floats
   float* As = lds;
-  float* Bs = lds + 2 * BM * LS;
-  float* tab = lds + 2 * (BM + BN) * LS;   // BNA: [3][C] = mean, a, beta of the producing layer
+  float* Bs = lds + NB * BM * LS;
+  float* tab = lds + NB * (BM + BN) * LS;   // BNA: [3][C] = mean, a, beta of the producing layer
 
   const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
   const int wg = xcd_remap(blockIdx.x, nbm * nbn);
@@ -439,10 +442,11 @@ void gemm_nt_kernel(GemmNTArgs p) {
     __syncthreads();
     if constexpr (!ACC2) {
       for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+        const int buf = kt & (NB - 1);
         if (kt + 1 < nk) load();
         compute(buf, acc, std::false_type{});
-        if (kt + 1 < nk) lstore(buf ^ 1);
+        if constexpr (NB == 1) __syncthreads();   // everybody has read the only buffer
+        if (kt + 1 < nk) lstore((kt + 1) & (NB - 1));
         __syncthreads();
       }
     } else {
@@ -452,8 +456,9 @@ void gemm_nt_kernel(GemmNTArgs p) {
 #pragma unroll
         for (int u = 0; u < FLUSH; ++u) {
           if (kt + u + 1 < nk) load();
-          if (u == 0) compute(0, part, std::true_type{}); else compute(u & 1, part, std::false_type{});
-          if (kt + u + 1 < nk) lstore((u & 1) ^ 1);
+          if (u == 0) compute(0, part, std::true_type{}); else compute(u & (NB - 1), part, std::false_type{});
+          if constexpr (NB == 1) __syncthreads();
+          if (kt + u + 1 < nk) lstore((u + 1) & (NB - 1));
           __syncthreads();
         }
 #pragma unroll
@@ -465,10 +470,11 @@ void gemm_nt_kernel(GemmNTArgs p) {
         f32x16 part[TM][TN];
         const int kt0 = kt;
         for (; kt < nk; ++kt) {
-          const int buf = kt & 1;
+          const int buf = kt & (NB - 1);
           if (kt + 1 < nk) load();
           if (kt == kt0) compute(buf, part, std::true_type{}); else compute(buf, part, std::false_type{});
-          if (kt + 1 < nk) lstore(buf ^ 1);
+          if constexpr (NB == 1) __syncthreads();
+          if (kt + 1 < nk) lstore((kt + 1) & (NB - 1));
           __syncthreads();
         }
 #pragma unroll
@@ -769,13 +775,16 @@ extern "C" int stil_gemm_nt_config(const float* A, const float* W, int M, int N,
   // 32-deep k-tiles: every staged row is one whole 128-byte line (16-deep tiles take half a line per k-tile and count on
   // L1 for the other half); with the 16-byte epilogue they win on the plain products with K >= 256 (+3..10 %,
   // profiles/r03_experiments.txt) although only 4 workgroups fit a CU, and lose on the conv gathers and the short ones.
-  const int bkd = (tune / 100) % 10;   // 0 automatic, 1 on, 2 off
-  const bool bk32 = (bkd == 1 || (bkd == 0 && plain && KH * KW == 1 && K >= 256 && !a_bn)) && (K % 32 == 0) && (KH * KW == 1 || srcC % 32 == 0);
+  const int bkd = (tune / 100) % 10;   // 0 automatic, 1 on (two LDS buffers), 2 off, 3 on with ONE LDS buffer
+  const bool bk32 = (bkd == 1 || bkd == 3 || (bkd == 0 && plain && KH * KW == 1 && !a_bn)) && (K % 32 == 0) && (KH * KW == 1 || srcC % 32 == 0);
+  // ... in ONE LDS buffer for the short plain products (K < 256: +3..7 %, as many workgroups per CU as 16-deep tiles), in
+  // two for the long ones (+3..10 %)
+  const bool single = bk32 && (bkd == 3 || (bkd == 0 && K < 256));
   const bool acc2 = tune / 1000 == 2 || (tune / 1000 == 0 && K >= 512);
   const bool vec = is_vec(A, lda) && (srcC % 4 == 0) && is_vec(W, ldb) && (K % 4 == 0);  // every 16-byte load aligned and entirely in or out
   if (a_bn)   // operand-staging BatchNorm: 64x64 tiles, BK = 16 (see stil_gemm_nt)
     return 11 + 1000 * (acc2 ? 1 : 0) + 10000 * (vec ? 1 : 0) + 100000 * ((plain && KH * KW == 1) ? 1 : 0) + 1000000;
-  return variant + 100 * ((vec && bk32) ? 1 : 0) + 1000 * (acc2 ? 1 : 0) + 10000 * (vec ? 1 : 0) + 100000 * ((plain && KH * KW == 1) ? 1 : 0);
+  return variant + 100 * ((vec && bk32) ? (single ? 2 : 1) : 0) + 1000 * (acc2 ? 1 : 0) + 10000 * (vec ? 1 : 0) + 100000 * ((plain && KH * KW == 1) ? 1 : 0);
 }
 
 extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, int lda, int ldb, int ldc,
@@ -787,7 +796,7 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   const int tune = tune_arg % 10000;                 // + 10000: scalar (one dword per lane) epilogue, for A/B measurements and tests
   const bool scalar_epilogue = tune_arg / 10000 == 1;
   STIL_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0, "stil_gemm_nt: null pointer or empty shape (M=%d N=%d K=%d)", M, N, K);
-  STIL_REQUIRE(tune_arg >= 0 && tune_arg < 20000 && tune < 3000 && (tune % 100 == 0 || tune % 100 == 11 || tune % 100 == 21 || tune % 100 == 22 || tune % 100 == 12) && (tune / 100) % 10 <= 2,
+  STIL_REQUIRE(tune_arg >= 0 && tune_arg < 20000 && tune < 3000 && (tune % 100 == 0 || tune % 100 == 11 || tune % 100 == 21 || tune % 100 == 22 || tune % 100 == 12) && (tune / 100) % 10 <= 3,
                "stil_gemm_nt: bad tune %d", tune);
   STIL_REQUIRE(KH * KW * srcC == K, "stil_gemm_nt: K=%d != KH*KW*C=%d", K, KH * KW * srcC);
   STIL_REQUIRE(M % (OH * OW) == 0, "stil_gemm_nt: M=%d not a multiple of OH*OW=%d", M, OH * OW);
@@ -815,7 +824,8 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   const bool plain = KH * KW == 1 && stride == 1 && pad_y == 0 && pad_x == 0 && mode == 0 && p.os == 1 && srcH == OH && srcW == OW;
   const int cfg = stil_gemm_nt_config(A, W, M, N, K, lda, ldb, srcC, KH, KW, plain ? 1 : 0, a_bn ? 1 : 0, tune);
   const int variant = cfg % 100;
-  const bool bk32 = (cfg / 100) % 10 == 1;   // BK = 32 halves the barriers per MFMA; needs whole taps and vector loads
+  const bool bk32 = (cfg / 100) % 10 >= 1;   // BK = 32: whole 128-byte lines per staged row; needs whole taps and vector loads
+  const bool single = (cfg / 100) % 10 == 2; // ... with one LDS buffer (64x64 tiles only)
   const bool acc2 = (cfg / 1000) % 10 == 1;  // long reductions: two-level accumulation (see gemm_nt_kernel)
   const bool vec = (cfg / 10000) % 10 == 1;
   rc = gemm_nt_attr();
@@ -843,6 +853,13 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   } while (0)
   if (!vec) {  // unaligned / ragged operands (K = 286 classifier gradients ...): scalar guarded loads
     if (variant == 11) LAUNCH_NT(1, 1, 16, false); else if (variant == 21) LAUNCH_NT(2, 1, 16, false); else if (variant == 12) LAUNCH_NT(1, 2, 16, false); else LAUNCH_NT(2, 2, 16, false);
+  } else if (variant == 11 && single) {
+    const dim3 grid_(cdiv(M, 64) * cdiv(N, 64));
+    const size_t lds_ = (size_t)64 * 2 * 36 * sizeof(float);
+    if (acc2 && plain) hipLaunchKernelGGL((gemm_nt_kernel<1, 1, 32, true, true, true, false, 1>), grid_, dim3(256), lds_, s, p);
+    else if (acc2) hipLaunchKernelGGL((gemm_nt_kernel<1, 1, 32, true, true, false, false, 1>), grid_, dim3(256), lds_, s, p);
+    else if (plain) hipLaunchKernelGGL((gemm_nt_kernel<1, 1, 32, true, false, true, false, 1>), grid_, dim3(256), lds_, s, p);
+    else hipLaunchKernelGGL((gemm_nt_kernel<1, 1, 32, true, false, false, false, 1>), grid_, dim3(256), lds_, s, p);
   } else if (variant == 11) { if (bk32) LAUNCH_NT(1, 1, 32, true); else LAUNCH_NT(1, 1, 16, true); }
   else if (variant == 12) { LAUNCH_NT(1, 2, 16, true); }
   else if (variant == 21) { if (bk32) LAUNCH_NT(2, 1, 32, true); else LAUNCH_NT(2, 1, 16, true); }

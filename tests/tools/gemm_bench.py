@@ -37,7 +37,7 @@ NT += [(50176, 256, 1024, 1, 1, 0, 14), (12544, 512, 2048, 1, 1, 0, 7), (12544, 
 def tune(v):
     return lambda: ops.TUNE.__setitem__("gemm", v)
 # tune = variant + 100 * bk32 + 1000 * acc2 (include/stil_hip.h): auto / single-chain accumulation / per tile variant
-variants = [("auto", tune(0)), ("bk32", tune(100))]
+variants = [("auto", tune(0)), ("bk16", tune(200)), ("bk32x2", tune(100)), ("bk32x1", tune(300))]
 res = {}
 for r in range(2):  # interleaved rounds
     for name, setter in variants:
@@ -91,7 +91,7 @@ for sh in [(50176, 256, 2304, 3, 1, 0, 14), (200704, 512, 128, 1, 1, 0, 28), (50
         A = torch.randn(Nb, H, H, C, device=dev); geom = (H, H, C, H, H, k, k, s, 1, 0)
     W = torch.randn(N, K, device=dev)
     outs = []
-    for v in (0, 10000, 21, 22):
+    for v in (0, 200, 100, 300):
         ops.TUNE["gemm"] = v
         outs.append(ops.gemm_nt(A, W, M, N, K, geom=geom).clone())
     torch.cuda.synchronize()
