@@ -39,10 +39,11 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 
 def kernel_name(cfg: int) -> str:
     """stil_gemm_nt_config code -> the template instantiation rocprofv3 lists."""
-    variant, bk32, acc2, vec, plain, bna = cfg % 100, (cfg // 100) % 10, (cfg // 1000) % 10, (cfg // 10000) % 10, (cfg // 100000) % 10, (cfg // 1000000) % 10
+    variant, bkd, acc2, vec, plain, bna = cfg % 100, (cfg // 100) % 10, (cfg // 1000) % 10, (cfg // 10000) % 10, (cfg // 100000) % 10, (cfg // 1000000) % 10
+    bk32, nb = bkd >= 1, (1 if bkd == 2 else 2)   # bkd: 0 = 16-deep k-tiles, 1 = 32-deep in two LDS buffers, 2 = 32-deep in one
     tm, tn = {22: (2, 2), 21: (2, 1), 12: (1, 2), 11: (1, 1)}[variant]
     b = lambda v: "true" if v else "false"  # noqa: E731
-    return f"gemm_nt_kernel<{tm}, {tn}, {32 if bk32 else 16}, {b(vec)}, {b(acc2)}, {b(plain)}, {b(bna)}>"
+    return f"gemm_nt_kernel<{tm}, {tn}, {32 if bk32 else 16}, {b(vec)}, {b(acc2)}, {b(plain)}, {b(bna)}, {nb}>"
 
 
 def parse():
