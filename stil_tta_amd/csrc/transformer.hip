@@ -324,7 +324,7 @@ __host__ __device__ static inline int attn_up16(int n) { return (n + 15) & ~15; 
 
 // rows [r0, r1) of a [*, d] matrix with row stride ld (floats) -> LDS rows of stride dp; rows >= nvalid are zero-filled
 __device__ __forceinline__ void attn_stage(float* dst, int dp, const float* src, long ld, int nvalid, int nrows, int d4) {
-  for (int i = threadIdx.x; i < nrows * d4; i += 256) {
+  for (int i = threadIdx.x; i < nrows * d4; i += blockDim.x) {
     const int r = i / d4, c = i - r * d4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < nvalid) v = *reinterpret_cast<const float4*>(src + (long)r * ld + c * 4);
@@ -377,12 +377,12 @@ __device__ __forceinline__ f32x4 attn_tile_tn(const float* X, int sx, const floa
 }
 
 // register prefetch of a [nvalid, d] matrix (row stride ld) for a later attn_unstage into LDS: NPF float4 per thread
-// cover nrows * d / 4 <= 256 * NPF elements (the launcher checks); rows >= nvalid read as zero
+// cover nrows * d / 4 <= blockDim.x * NPF elements (the launcher checks); rows >= nvalid read as zero
 template <int NPF>
 __device__ __forceinline__ void attn_prefetch(float4 (&r)[NPF], const float* src, long ld, int nvalid, int nrows, int d4) {
 #pragma unroll
   for (int u = 0; u < NPF; ++u) {
-    const int i = threadIdx.x + 256 * u;
+    const int i = threadIdx.x + blockDim.x * u;
     const int row = i / d4, c = i - row * d4;
     r[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < nrows * d4 && row < nvalid) r[u] = *reinterpret_cast<const float4*>(src + (long)row * ld + c * 4);
@@ -392,14 +392,19 @@ template <int NPF>
 __device__ __forceinline__ void attn_unstage(float* dst, int dp, const float4 (&r)[NPF], int nrows, int d4) {
 #pragma unroll
   for (int u = 0; u < NPF; ++u) {
-    const int i = threadIdx.x + 256 * u;
+    const int i = threadIdx.x + blockDim.x * u;
     const int row = i / d4, c = i - row * d4;
     if (i < nrows * d4) *reinterpret_cast<float4*>(dst + row * dp + c * 4) = r[u];
   }
 }
-constexpr int ATTN_NPF = 16;   // up to 128 rows x 128 floats (or 256 x 64) per prefetched matrix
+constexpr int ATTN_NPF = 16;   // 256-thread workgroups: up to 128 rows x 128 floats (or 256 x 64) per prefetched matrix; NT threads: 16 * 256 / NT
 
-__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs p) {
+// NT threads = NT / 64 waves per (batch, head): every phase deals its 16x16 tiles round-robin over the waves, so a 512-thread
+// workgroup walks each phase in half the tile-steps with the same LDS footprint -- twice the waves per CU for a kernel that is
+// bound by its own latency chain at 2 workgroups per CU (used when a phase has >= 16 tiles).
+template <int NT>
+__global__ __launch_bounds__(NT) void attn_fwd_mfma_kernel(AttnArgs p) {
+  constexpr int NW = NT / 64, NPF = ATTN_NPF * 256 / NT;
   extern __shared__ __attribute__((aligned(16))) float sh[];
   const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
   const int d = p.d, d4 = d >> 2, Sq = p.Sq, Skv = p.Skv, SqP = attn_up16(Sq), SkP = attn_up16(Skv);
@@ -410,23 +415,23 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs p) {
   const long ld = 3L * p.H * d;
   const float* base = p.qkv + (long)b * p.T * ld + h * d;
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-  float4 vreg[ATTN_NPF];
+  float4 vreg[NPF];
   attn_stage(Qs, dq, base + (long)p.q_off * ld, ld, Sq, SqP, d4);
   attn_stage(KV, dq, base + (long)p.kv_off * ld + p.H * d, ld, Skv, SkP, d4);
-  attn_prefetch<ATTN_NPF>(vreg, base + (long)p.kv_off * ld + 2 * p.H * d, ld, Skv, SkP, d4);   // V: in flight under Q K^T
+  attn_prefetch<NPF>(vreg, base + (long)p.kv_off * ld + 2 * p.H * d, ld, Skv, SkP, d4);   // V: in flight under Q K^T
   __syncthreads();
   const int ntq = SqP >> 4, ntk = SkP >> 4, ntc = d >> 4;
-  for (int t = w; t < ntq * ntk; t += 4) {                       // S = scale * Q K^T
+  for (int t = w; t < ntq * ntk; t += NW) {                       // S = scale * Q K^T
     const int ti = t / ntk, tj = t - ti * ntk;
     const f32x4 acc = attn_tile_nt(Qs, dq, KV, dq, ti, tj, d, lane);
 #pragma unroll
     for (int r = 0; r < 4; ++r) Ps[(ti * 16 + (lane >> 4) * 4 + r) * sp + tj * 16 + (lane & 15)] = acc[r] * p.scale;
   }
   __syncthreads();
-  attn_unstage<ATTN_NPF>(KV, dp, vreg, SkP, d4);                 // V overwrites K
+  attn_unstage<NPF>(KV, dp, vreg, SkP, d4);                 // V overwrites K
   float* pg = p.probs + ((long)(b * p.H + h) * Sq) * Skv;
   const unsigned char* mk = p.mask ? p.mask + ((long)(b * p.H + h) * Sq) * Skv : nullptr;
-  for (int i = w; i < Sq; i += 4) {                              // softmax over the valid columns; padding stays 0
+  for (int i = w; i < Sq; i += NW) {                              // softmax over the valid columns; padding stays 0
     float* pr = Ps + i * sp;
     float m = -INFINITY;
     for (int j = lane; j < Skv; j += 64) m = fmaxf(m, pr[j]);
@@ -444,7 +449,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs p) {
   }
   __syncthreads();
   float* ob = p.out + ((long)b * p.T + p.q_off) * (p.H * d) + h * d;
-  for (int t = w; t < ntq * ntc; t += 4) {                       // O = P V
+  for (int t = w; t < ntq * ntc; t += NW) {                       // O = P V
     const int ti = t / ntc, tc = t - ti * ntc;
     const f32x4 acc = attn_tile_nn(Ps, sp, KV, dp, ti, tc, SkP, lane);
 #pragma unroll
@@ -458,7 +463,9 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs p) {
 // stride for matrices that are only read "row = l >> 4, column = l & 15" (B operands K, Q of the last phase): == 16 (mod 64)
 __host__ __device__ static inline int attn_padT(int d) { return ((d - 16 + 63) / 64) * 64 + 16; }
 
-__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs p) {
+template <int NT>
+__global__ __launch_bounds__(NT) void attn_bwd_mfma_kernel(AttnArgs p) {
+  constexpr int NW = NT / 64, NPF = ATTN_NPF * 256 / NT;
   extern __shared__ __attribute__((aligned(16))) float sh[];
   const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
   const int d = p.d, d4 = d >> 2, Sq = p.Sq, Skv = p.Skv, SqP = attn_up16(Sq), SkP = attn_up16(Skv);
@@ -475,10 +482,10 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs p) {
   const float* pg = p.probs + ((long)(b * p.H + h) * Sq) * Skv;
   const unsigned char* mk = p.mask ? p.mask + ((long)(b * p.H + h) * Sq) * Skv : nullptr;
   const int ntq = SqP >> 4, ntk = SkP >> 4, ntc = d >> 4;
-  float4 kreg[ATTN_NPF], qreg[ATTN_NPF];
+  float4 kreg[NPF], qreg[NPF];
   attn_stage(R0, dp, dob, (long)p.H * d, Sq, SqP, d4);
   attn_stage(R1, dq, base + (long)p.kv_off * ld + 2 * p.H * d, ld, Skv, SkP, d4);
-  for (int e = tid; e < SqP * SkP; e += 256) {                   // Pd = P * keep (zero in the padding)
+  for (int e = tid; e < SqP * SkP; e += NT) {                   // Pd = P * keep (zero in the padding)
     const int i = e / SkP, j = e - i * SkP;
     float v = 0.f;
     if (i < Sq && j < Skv) {
@@ -487,10 +494,10 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs p) {
     }
     X[i * sp + j] = v;
   }
-  attn_prefetch<ATTN_NPF>(kreg, base + (long)p.kv_off * ld + p.H * d, ld, Skv, SkP, d4);   // K, Q: needed only by the last phase
-  attn_prefetch<ATTN_NPF>(qreg, base + (long)p.q_off * ld, ld, Sq, SqP, d4);
+  attn_prefetch<NPF>(kreg, base + (long)p.kv_off * ld + p.H * d, ld, Skv, SkP, d4);   // K, Q: needed only by the last phase
+  attn_prefetch<NPF>(qreg, base + (long)p.q_off * ld, ld, Sq, SqP, d4);
   __syncthreads();
-  for (int t = w; t < ntk * ntc; t += 4) {                       // dV += Pd^T dO
+  for (int t = w; t < ntk * ntc; t += NW) {                       // dV += Pd^T dO
     const int tj = t / ntc, tc = t - tj * ntc;
     const f32x4 acc = attn_tile_tn(X, sp, R0, dp, tj, tc, SqP, lane);
 #pragma unroll
@@ -500,7 +507,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs p) {
     }
   }
   __syncthreads();                                               // Pd is dead: X is free for dP
-  for (int t = w; t < ntq * ntk; t += 4) {                       // dP = (dO V^T) * keep
+  for (int t = w; t < ntq * ntk; t += NW) {                       // dP = (dO V^T) * keep
     const int ti = t / ntk, tj = t - ti * ntk;
     const f32x4 acc = attn_tile_nt(R0, dp, R1, dq, ti, tj, d, lane);
     const int j = tj * 16 + (lane & 15);
@@ -513,16 +520,16 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs p) {
     }
   }
   __syncthreads();                                               // dO and V are dead: R0 / R1 take Q / K
-  attn_unstage<ATTN_NPF>(R1, dt, kreg, SkP, d4);
-  attn_unstage<ATTN_NPF>(R0, dt, qreg, SqP, d4);
-  for (int i = w; i < Sq; i += 4) {                              // dS = P * (dP - rowsum(dP * P)) * scale
+  attn_unstage<NPF>(R1, dt, kreg, SkP, d4);
+  attn_unstage<NPF>(R0, dt, qreg, SqP, d4);
+  for (int i = w; i < Sq; i += NW) {                              // dS = P * (dP - rowsum(dP * P)) * scale
     float sacc = 0.f;
     for (int j = lane; j < Skv; j += 64) sacc += X[i * sp + j] * pg[(long)i * Skv + j];
     sacc = wave_sum(sacc);
     for (int j = lane; j < Skv; j += 64) X[i * sp + j] = pg[(long)i * Skv + j] * (X[i * sp + j] - sacc) * p.scale;
   }
   __syncthreads();
-  for (int t = w; t < ntq * ntc; t += 4) {                       // dQ += dS K
+  for (int t = w; t < ntq * ntc; t += NW) {                       // dQ += dS K
     const int ti = t / ntc, tc = t - ti * ntc;
     const f32x4 acc = attn_tile_nn(X, sp, R1, dt, ti, tc, SkP, lane);
 #pragma unroll
@@ -531,7 +538,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs p) {
       if (i < Sq) dbase[(long)(p.q_off + i) * ld + tc * 16 + (lane & 15)] += acc[r];
     }
   }
-  for (int t = w; t < ntk * ntc; t += 4) {                       // dK += dS^T Q   (other slot of dqkv than dQ: no hazard)
+  for (int t = w; t < ntk * ntc; t += NW) {                       // dK += dS^T Q   (other slot of dqkv than dQ: no hazard)
     const int tj = t / ntc, tc = t - tj * ntc;
     const f32x4 acc = attn_tile_tn(X, sp, R0, dt, tj, tc, SqP, lane);
 #pragma unroll
@@ -823,13 +830,18 @@ static bool attn_mfma_ok(int Sq, int Skv, int d, size_t lds) {
   return d % 16 == 0 && d >= 16 && lds <= 160 * 1024 && Sq > 0 && Skv > 0 && (long)big * (d / 4) <= 256L * ATTN_NPF;
 }
 
+// 8 waves per (batch, head) once the score matrix has >= 16 tiles of 16 x 16
+static bool attn_big_wg(int Sq, int Skv) { return (attn_up16(Sq) >> 4) * (attn_up16(Skv) >> 4) >= 16; }
+
 static bool g_attn_attr_set = false;
 static int attn_set_attr() {
   if (g_attn_attr_set) return STIL_OK;
   hipError_t e1 = hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipError_t e2 = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e1 != hipSuccess || e2 != hipSuccess) {
     stil_set_error("attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     return STIL_EHIP;
@@ -847,14 +859,16 @@ extern "C" int stil_attention_fwd(const float* qkv, float* out, float* probs, co
   size_t lds = ((size_t)Sq * d + (size_t)Skv * (d + 4) + (size_t)Sq * Skv) * sizeof(float);
   const size_t lds_m = attn_mfma_lds(Sq, Skv, d, false);   // MFMA path: d % 16 == 0 and its padded tiles fit
   // matrix-pipe kernel unless it would keep fewer workgroups resident than the VALU kernel (both are latency-bound)
-  const bool mfma = attn_mfma_ok(Sq, Skv, d, lds_m) && (lds > 160 * 1024 || (160 * 1024) / lds_m >= (160 * 1024) / lds);
+  const bool big = attn_big_wg(Sq, Skv);   // 8-wave matrix-pipe workgroups: twice the waves of the VALU kernel's even at one workgroup fewer
+  const bool mfma = attn_mfma_ok(Sq, Skv, d, lds_m) && (lds > 160 * 1024 || big || (160 * 1024) / lds_m >= (160 * 1024) / lds);
   STIL_REQUIRE(mfma || lds <= 160 * 1024, "stil_attention_fwd: needs %zu B of LDS (> 160 KiB): Sq=%d Skv=%d d=%d", lds, Sq, Skv, d);
   if ((rc = attn_set_attr())) return rc;
   AttnArgs p;
   p.qkv = qkv; p.out = out; p.probs = probs; p.mask = mask; p.dout = nullptr; p.dqkv = nullptr;
   p.B = B; p.T = T; p.H = H; p.d = d; p.q_off = q_off; p.Sq = Sq; p.kv_off = kv_off; p.Skv = Skv;
   p.scale = scale; p.drop_scale = mask ? 1.f / (1.f - drop_p) : 1.f;
-  if (mfma) hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(B * H), dim3(256), lds_m, (hipStream_t)stream, p);
+  if (mfma && big) hipLaunchKernelGGL(attn_fwd_mfma_kernel<512>, dim3(B * H), dim3(512), lds_m, (hipStream_t)stream, p);
+  else if (mfma) hipLaunchKernelGGL(attn_fwd_mfma_kernel<256>, dim3(B * H), dim3(256), lds_m, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, p);
   STIL_LAUNCH_CHECK();
   return STIL_OK;
@@ -870,14 +884,16 @@ extern "C" int stil_attention_bwd(const float* dout, const float* qkv, const flo
   size_t lds = ((size_t)2 * Smax * (d + 4) + (size_t)2 * Sq * Skv) * sizeof(float);
   const size_t lds_m = attn_mfma_lds(Sq, Skv, d, true);
   // matrix-pipe kernel unless it would keep fewer workgroups resident than the VALU kernel (both are latency-bound)
-  const bool mfma = attn_mfma_ok(Sq, Skv, d, lds_m) && (lds > 160 * 1024 || (160 * 1024) / lds_m >= (160 * 1024) / lds);
+  const bool big = attn_big_wg(Sq, Skv);
+  const bool mfma = attn_mfma_ok(Sq, Skv, d, lds_m) && (lds > 160 * 1024 || big || (160 * 1024) / lds_m >= (160 * 1024) / lds);
   STIL_REQUIRE(mfma || lds <= 160 * 1024, "stil_attention_bwd: needs %zu B of LDS (> 160 KiB)", lds);
   if ((rc = attn_set_attr())) return rc;
   AttnArgs p;
   p.qkv = qkv; p.out = nullptr; p.probs = const_cast<float*>(probs); p.mask = mask; p.dout = dout; p.dqkv = dqkv;
   p.B = B; p.T = T; p.H = H; p.d = d; p.q_off = q_off; p.Sq = Sq; p.kv_off = kv_off; p.Skv = Skv;
   p.scale = scale; p.drop_scale = mask ? 1.f / (1.f - drop_p) : 1.f;
-  if (mfma) hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(B * H), dim3(256), lds_m, (hipStream_t)stream, p);
+  if (mfma && big) hipLaunchKernelGGL(attn_bwd_mfma_kernel<512>, dim3(B * H), dim3(512), lds_m, (hipStream_t)stream, p);
+  else if (mfma) hipLaunchKernelGGL(attn_bwd_mfma_kernel<256>, dim3(B * H), dim3(256), lds_m, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, p);
   STIL_LAUNCH_CHECK();
   return STIL_OK;
