@@ -46,7 +46,12 @@ int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, 
                  int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad_y, int pad_x,
                  int mode, int out_stride, int out_py, int out_px, int out_OH, int out_OW,
                  const float* bias, const float* sub, const float* scale, const float* shift, const float* resid,
-                 int ldr, float* pre, int act, float alpha, float* colstats, const float* a_bn, int tune, void* stream);
+                 int ldr, float* pre, int act, float alpha, float* colstats, const float* a_bn, const float* relu_mask, int ldm,
+                 int tune, void* stream);
+/* `relu_mask` (optional, row stride ldm, shaped like C): the stored value is zeroed where relu_mask <= 0.  The input-gradient
+ *   GEMM of a block's first conv writes the gradient of the PREVIOUS block's output already multiplied by that output's ReLU
+ *   mask (models/resnets.py:129-130: out += identity; out = relu(out)), so that block's BatchNorm backward neither reads z
+ *   nor materialises the masked gradient. */
 /* `a_bn` (optional; forward gathers with srcC % 16 == 0, 16-byte aligned operands): the A source is the RAW output y of a
  *   training conv+BN+ReLU layer and a_bn that layer's statistics block [4][srcC] (mean, rstd, a = gamma * rstd, beta, as
  *   stil_bn_train_fwd_tiles writes it); z = relu((y - mean) * a + beta) is formed while A is staged, so the inner layers of a

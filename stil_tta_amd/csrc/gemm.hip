@@ -52,6 +52,8 @@ struct GemmNTArgs {
   // of a bottleneck reads the raw conv output y of the layer before it; z = relu((y - mean) * a + beta) is never
   // materialised): abn = that layer's statistics block [4][C] = mean, rstd, a = gamma * rstd, beta (bn.hip)
   const float* abn;
+  const float* rmask;  // optional [rows, ldc]-shaped tensor (row stride ldm): the stored value is zeroed where rmask <= 0 -- the ReLU
+  int ldm;             // mask of the block output whose gradient this launch produces (pre-masked residual gradient)
   int wide;   // 1: 16-byte epilogue (64x64 tiles; N, ldc, ldr % 4 == 0 and C / resid / pre / per-column vectors 16-byte aligned)
 };
 
@@ -185,6 +187,10 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNTArgs& p, f32x16 (&a
           if (p.pre) *reinterpret_cast<float4*>(p.pre + row * p.ldc + col) = v;
           if (p.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
           else if (p.act == 2) { v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w); }
+          if (p.rmask) {
+            const float4 mk = *reinterpret_cast<const float4*>(p.rmask + row * p.ldm + col);
+            v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+          }
           *reinterpret_cast<float4*>(p.C + row * p.ldc + col) = v;
         }
       }
@@ -220,6 +226,7 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNTArgs& p, f32x16 (&a
         if (p.pre) p.pre[row * p.ldc + col] = v;
         if (p.act == 1) v = fmaxf(v, 0.f);
         else if (p.act == 2) v = gelu_f(v);
+        if (p.rmask) v = p.rmask[row * p.ldm + col] > 0.f ? v : 0.f;
         p.C[row * p.ldc + col] = v;
       }
     }
@@ -792,7 +799,7 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
                             int pad_x, int mode, int out_stride, int out_py, int out_px, int out_OH, int out_OW,
                             const float* bias, const float* sub, const float* scale,
                             const float* shift, const float* resid, int ldr, float* pre, int act, float alpha,
-                            float* colstats, const float* a_bn, int tune_arg, void* stream) {
+                            float* colstats, const float* a_bn, const float* relu_mask, int ldm, int tune_arg, void* stream) {
   const int tune = tune_arg % 10000;                 // + 10000: scalar (one dword per lane) epilogue, for A/B measurements and tests
   const bool scalar_epilogue = tune_arg / 10000 == 1;
   STIL_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0, "stil_gemm_nt: null pointer or empty shape (M=%d N=%d K=%d)", M, N, K);
@@ -808,9 +815,11 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   p.alpha = alpha;
   p.colstats = colstats;
   p.abn = a_bn;
+  p.rmask = relu_mask; p.ldm = ldm;
+  STIL_REQUIRE(!relu_mask || !colstats, "stil_gemm_nt: relu_mask and colstats exclude each other");
   {
     auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q % 16) == 0; };
-    p.wide = (N % 4 == 0) && (ldc % 4 == 0) && (!resid || ldr % 4 == 0) && al16(C) && al16(resid) && al16(pre) && al16(bias) && al16(sub) &&
+    p.wide = (N % 4 == 0) && (ldc % 4 == 0) && (!resid || ldr % 4 == 0) && (!relu_mask || ldm % 4 == 0) && al16(relu_mask) && al16(C) && al16(resid) && al16(pre) && al16(bias) && al16(sub) &&
              al16(scale) && al16(shift) && !scalar_epilogue ? 1 : 0;
   }
   STIL_REQUIRE(!colstats || (p.os == 1 && !bias && !sub && !scale && !shift && !resid && act == 0),

@@ -57,7 +57,7 @@ def set_teacher_pipe(pipe: Optional[TeacherPipe]):
 
 
 def _conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool, train: bool, resid=None, stem=None, passthrough=False, defer=False,
-             xstats=None):
+             xstats=None, premask_in=None, premask_out=None):
     """passthrough (first conv of a residual block): -> (out, alias of x) so the identity branch's gradient is folded
     into this conv's input-gradient GEMM (ops.ConvBnActFn).
     defer (training, inner layers of a block): -> (..., stats) with out = the RAW conv output; the next conv gets them as
@@ -67,7 +67,8 @@ def _conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool, train: bool, re
     pipe = _PIPE
     if train:
         out = ops.ConvBnActFn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                    bn.num_batches_tracked, resid, k, stride, pad, relu, stem, passthrough, defer, xstats)
+                                    bn.num_batches_tracked, resid, k, stride, pad, relu, stem, passthrough, defer, xstats,
+                                    premask_in, premask_out)
         if pipe is not None:
             pipe.published()
         return out
@@ -96,10 +97,13 @@ class Bottleneck(nn.Module):  # models/resnets.py:91-132
         d1 = train and ops.can_defer_bn(self.conv1.out_channels)   # bn1 + relu applied inside conv2's operand staging
         d2 = train and ops.can_defer_bn(self.conv2.out_channels)   # bn2 + relu applied inside conv3's operand staging
         st1 = st2 = None
+        pm = train and ops._PREMASK
+        cin = getattr(x, "_stil_premask", None) if pm else None   # x is the previous block's relu output: hand its gradient back masked
+        cout = {} if pm else None
         if d1:
-            out, identity, st1 = _conv_bn(x, self.conv1, self.bn1, True, train, passthrough=True, defer=True)
+            out, identity, st1 = _conv_bn(x, self.conv1, self.bn1, True, train, passthrough=True, defer=True, premask_in=cin)
         else:
-            out, identity = _conv_bn(x, self.conv1, self.bn1, True, train, passthrough=True)
+            out, identity = _conv_bn(x, self.conv1, self.bn1, True, train, passthrough=True, premask_in=cin)
         if d2:
             out, st2 = _conv_bn(out, self.conv2, self.bn2, True, train, defer=True, xstats=st1)
         else:
@@ -107,7 +111,10 @@ class Bottleneck(nn.Module):  # models/resnets.py:91-132
         if self.downsample is not None:
             identity = _conv_bn(identity, self.downsample[0], self.downsample[1], False, train)
         Nb, H, W, C = identity.shape
-        return _conv_bn(out, self.conv3, self.bn3, True, train, resid=identity.reshape(Nb * H * W, C), xstats=st2)
+        out = _conv_bn(out, self.conv3, self.bn3, True, train, resid=identity.reshape(Nb * H * W, C), xstats=st2, premask_out=cout)
+        if cout is not None:
+            out._stil_premask = cout   # the next block's first conv (the only consumer of `out`) picks it up
+        return out
 
 
 class BasicBlock(nn.Module):  # models/resnets.py:50-88
@@ -123,14 +130,20 @@ class BasicBlock(nn.Module):  # models/resnets.py:50-88
 
     def run(self, x, train):
         st1 = None
+        pm = train and ops._PREMASK
+        cin = getattr(x, "_stil_premask", None) if pm else None
+        cout = {} if pm else None
         if train and ops.can_defer_bn(self.conv1.out_channels):     # bn1 + relu applied inside conv2's operand staging
-            out, identity, st1 = _conv_bn(x, self.conv1, self.bn1, True, train, passthrough=True, defer=True)
+            out, identity, st1 = _conv_bn(x, self.conv1, self.bn1, True, train, passthrough=True, defer=True, premask_in=cin)
         else:
-            out, identity = _conv_bn(x, self.conv1, self.bn1, True, train, passthrough=True)
+            out, identity = _conv_bn(x, self.conv1, self.bn1, True, train, passthrough=True, premask_in=cin)
         if self.downsample is not None:
             identity = _conv_bn(identity, self.downsample[0], self.downsample[1], False, train)
         Nb, H, W, C = identity.shape
-        return _conv_bn(out, self.conv2, self.bn2, True, train, resid=identity.reshape(Nb * H * W, C), xstats=st1)
+        out = _conv_bn(out, self.conv2, self.bn2, True, train, resid=identity.reshape(Nb * H * W, C), xstats=st1, premask_out=cout)
+        if cout is not None:
+            out._stil_premask = cout
+        return out
 
 
 class ResNet(nn.Module):

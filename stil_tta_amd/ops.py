@@ -151,7 +151,7 @@ def _grad_into(param: torch.Tensor, writer):
 
 # ------------------------------------------------------------------------------------------ raw wrappers
 def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None, bias=None, sub=None, scale=None, shift=None,
-            resid=None, pre=None, act=0, alpha=1.0, pads=None, outmap=None, out_rows=None, colstats=None, a_bn=None):
+            resid=None, pre=None, act=0, alpha=1.0, pads=None, outmap=None, out_rows=None, colstats=None, a_bn=None, relu_mask=None):
     """C = epilogue(alpha * Agather . W^T).  geom = (srcH, srcW, srcC, OH, OW, KH, KW, stride, pad, mode);
     pads = (pad_y, pad_x) overrides geom's pad; outmap = (out_stride, py, px, out_OH, out_OW) scatters GEMM row
     (n, oy, ox) to output row (n*out_OH + oy*s + py)*out_OW + ox*s + px (out_rows = rows of `out` then)."""
@@ -176,7 +176,8 @@ def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None,
         meta = (cfg, 2.0 * M * N * K / s2, (M, N, K, geom[5], geom[7], geom[9]), nbytes)
     L.gemm_nt(_p(A), _p(W), _p(out), M, N, K, lda, ldb, ldc, *geom[:8], pads[0], pads[1], geom[9], *outmap,
               _p(bias), _p(sub), _p(scale), _p(shift), _p(resid),
-              (ldc if resid is not None else 0), _p(pre), act, float(alpha), _p(colstats), _p(a_bn), TUNE["gemm"], _stream(), meta=meta)
+              (ldc if resid is not None else 0), _p(pre), act, float(alpha), _p(colstats), _p(a_bn), _p(relu_mask),
+              (ldc if relu_mask is not None else 0), TUNE["gemm"], _stream(), meta=meta)
     return out
 
 
@@ -322,6 +323,7 @@ _BN_EPILOGUE_STATS = __import__("os").environ.get("STIL_BN_EPILOGUE_STATS", "1")
 
 
 _BN_DEFER = __import__("os").environ.get("STIL_BN_DEFER", "1") != "0"
+_PREMASK = __import__("os").environ.get("STIL_PREMASK", "1") != "0"   # residual gradients leave the next block's dgrad GEMM pre-masked
 
 
 def can_defer_bn(Cout: int) -> bool:
@@ -338,7 +340,8 @@ class ConvBnActFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, rmean, rvar, nbt, resid, k, stride, pad, relu, stem, passthrough=False, defer=False, xstats=None):
+    def forward(ctx, x, w, gamma, beta, rmean, rvar, nbt, resid, k, stride, pad, relu, stem, passthrough=False, defer=False, xstats=None,
+                premask_in=None, premask_out=None):
         """passthrough: also return x itself as a second output.  A residual block routes its identity branch through
         that alias, so the branch's gradient arrives HERE and is added inside the input-gradient GEMM's epilogue
         instead of by a separate accumulation kernel of the autograd engine.
@@ -347,7 +350,12 @@ class ConvBnActFn(torch.autograd.Function):
         passes them back as `xstats` and forms z = relu((y - mean) * a + beta) while it stages its operand (forward
         GEMM and weight-gradient GEMM: stil_gemm_nt a_bn / stil_wgrad_tn x_bn), so z is never written or read.  The
         gradient this node receives is still the one w.r.t. z: its backward is unchanged (the ReLU mask is recomputed
-        from y and the statistics, bn_train_bwd relu = 2)."""
+        from y and the statistics, bn_train_bwd relu = 2).
+        premask_out / premask_in (a shared dict per block output z = relu(bn3(y3) + identity)): the block's last node
+        publishes the dict, the NEXT block's first node -- the only consumer of z -- receives it.  That node's input-gradient
+        GEMM then writes dL/dz already multiplied by the ReLU mask (z > 0), read in its 16-byte epilogue (stil_gemm_nt
+        relu_mask), and says so in the dict; this node's BatchNorm backward then takes the gradient as it comes: it neither
+        reads z nor materialises the masked gradient for the identity branch (one wide-tensor pass fewer per block)."""
         _chk(x, w, gamma, beta, resid)
         ctx.set_materialize_grads(False)
         assert not defer or (relu and resid is None), "only conv+BN+ReLU layers without a residual can defer their BatchNorm"
@@ -397,6 +405,8 @@ class ConvBnActFn(torch.autograd.Function):
         ctx.save_for_backward(x, w, gamma, beta, y, None if defer else z, stats, xstats)
         ctx.cfg = (k, stride, pad, relu, stem is not None, resid is not None, geom, (Nb, OH, OW), stem)
         ctx.has_alias = bool(passthrough)
+        ctx.premask_in = premask_in if (stem is None and stride == 1) else None     # only the plain / stride-1 gather dgrad GEMMs mask
+        ctx.premask_out = premask_out if (relu and resid is not None and not defer) else None
         out = (y if defer else z).view(Nb, OH, OW, Cout)
         if defer:
             ctx.mark_non_differentiable(stats)
@@ -416,7 +426,8 @@ class ConvBnActFn(torch.autograd.Function):
         M = Nb * OH * OW
         gz = gz.contiguous()
         dy = torch.empty((M, Cout), dtype=torch.float32, device=dev)
-        gres = torch.empty((M, Cout), dtype=torch.float32, device=dev) if (has_res and relu) else None
+        premasked = ctx.premask_out is not None and ctx.premask_out.get("masked", False)   # gz already carries the (z > 0) mask
+        gres = torch.empty((M, Cout), dtype=torch.float32, device=dev) if (has_res and relu and not premasked) else None
         coef = torch.empty((3, Cout), dtype=torch.float32, device=dev)
         nb = lib().bn_workspace_bytes(M, Cout)
         ws = _ws.get(nb, dev)
@@ -425,12 +436,12 @@ class ConvBnActFn(torch.autograd.Function):
         dbeta = bslot if bslot is not None else torch.empty_like(beta)
         acc = 1 if gslot is not None else 0
         lib().bn_train_bwd(_p(gz), _p(z), _p(y), _p(gamma), _p(stats), _p(dy), _p(gres), _p(dgamma), _p(dbeta), _p(coef), M,
-                           Cout, (1 if has_res else 2) if relu else 0, acc, _p(ws), nb, _stream())
+                           Cout, 0 if premasked else ((1 if has_res else 2) if relu else 0), acc, _p(ws), nb, _stream())
         if gslot is not None:
             _touch(gamma)
             _touch(beta)
         if has_res:
-            dres = gres if relu else gz.view(M, Cout)
+            dres = gres if (relu and not premasked) else gz.view(M, Cout)
         else:
             dres = None
         dx = None
@@ -442,14 +453,20 @@ class ConvBnActFn(torch.autograd.Function):
             _, H, W_, Cin = x.shape
             if ctx.needs_input_grad[0]:
                 ga = None if gx_alias is None else gx_alias.contiguous().view(Nb * H * W_, Cin)
+                # x is the previous block's output z = relu(.): its consumer is this node alone, so the gradient can leave
+                # here already masked (the identity branch's share arrives through `ga` and is masked with it)
+                cell = ctx.premask_in if (ctx.premask_in is not None and xstats is None and Cin % 4 == 0 and stride == 1) else None
+                zmask = x.view(Nb * H * W_, Cin) if cell is not None else None
+                if cell is not None:
+                    cell["masked"] = True   # both stride-1 branches below apply the mask
                 if k == 1 and stride == 1:
                     wd = transpose(w.reshape(Cout, Cin))  # [Cin, Cout]
-                    dx = gemm_nt(dy, wd, M, Cin, Cout, resid=ga).view(Nb, H, W_, Cin)
+                    dx = gemm_nt(dy, wd, M, Cin, Cout, resid=ga, relu_mask=zmask).view(Nb, H, W_, Cin)
                 elif stride == 1:
                     wd = torch.empty((Cin, k * k * Cout), dtype=torch.float32, device=dev)
                     lib().conv_weight_layout(_p(w), None, _p(wd), Cout, Cin, k, k, _stream())
                     g2 = (OH, OW, Cout, H, W_, k, k, stride, pad, 1)
-                    dx = gemm_nt(dy, wd, Nb * H * W_, Cin, k * k * Cout, geom=g2, resid=ga).view(Nb, H, W_, Cin)
+                    dx = gemm_nt(dy, wd, Nb * H * W_, Cin, k * k * Cout, geom=g2, resid=ga, relu_mask=zmask).view(Nb, H, W_, Cin)
                 else:
                     dx = strided_dgrad(dy, w, Nb, H, W_, Cin, OH, OW, Cout, k, stride, pad)
                     if ga is not None:
@@ -459,7 +476,7 @@ class ConvBnActFn(torch.autograd.Function):
             gw = geom[:9]
             dw = wgrad_param(w, dy, x, M, Cout, k * k * Cin, geom=gw, x_bn=xstats)
         return (dx, dw, (None if gslot is not None else dgamma), (None if bslot is not None else dbeta), None, None, None,
-                dres, None, None, None, None, None, None, None, None)
+                dres, None, None, None, None, None, None, None, None, None, None)
 
 
 def strided_dgrad(dy, w, Nb, H, W_, Cin, OH, OW, Cout, k, stride, pad):

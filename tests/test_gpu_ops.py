@@ -241,6 +241,37 @@ def test_deferred_batchnorm_is_the_materialised_path_bit_for_bit(ops, C1, C2, k2
     close(b[3], g1r.grad, tol=5e-5, name="dgamma1 vs ATen")
 
 
+@pytest.mark.parametrize("arch", ["resnet50", "resnet18"])
+def test_premasked_residual_gradient_and_deferred_bn_equal_the_plain_blocks(ops, arch):
+    """models/resnets.py:112-132 over a stack of residual blocks (layer1 + layer2 of the trunk: identity and downsample
+    shortcuts, stride-2 stage boundary).  Production path: inner BatchNorms in the consumer's operand staging, and every block
+    output's gradient leaving the next block's input-gradient GEMM already multiplied by the ReLU mask (stil_gemm_nt
+    relu_mask).  Against the same blocks with both switched off: outputs, BN buffers and every parameter gradient bit for bit."""
+    from stil_tta_amd.modules import ResNet
+    res = []
+    for fused in (True, False):
+        ops._BN_DEFER, ops._PREMASK = fused, fused
+        try:
+            torch.manual_seed(5)
+            net = ResNet(arch).cuda()
+            blocks = list(net.layer1) + list(net.layer2)
+            x = torch.randn(4, 12, 12, 64, generator=torch.Generator().manual_seed(1)).cuda().requires_grad_()
+            h = x
+            for blk in blocks:
+                h = blk.run(h, True)
+            gy = torch.randn(h.shape, generator=torch.Generator().manual_seed(2)).cuda()
+            h.backward(gy)
+            torch.cuda.synchronize()
+            ps = [p for blk in blocks for p in blk.parameters()]
+            bufs = [b for blk in blocks for b in blk.buffers()]
+            res.append([h.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in ps] + [b.clone() for b in bufs])
+        finally:
+            ops._BN_DEFER, ops._PREMASK = True, True
+    assert len(res[0]) == len(res[1]) > 20
+    for i, (u, v) in enumerate(zip(*res)):
+        assert torch.equal(u, v), f"tensor {i}: fused blocks differ from the plain ones (max |d| = {float((u.float() - v.float()).abs().max()):.3e})"
+
+
 def test_stem_and_maxpool(ops):
     g = torch.Generator().manual_seed(5)
     Nb, H = 3, 40
