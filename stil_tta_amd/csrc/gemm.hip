@@ -672,20 +672,27 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ P, float* __restri
   long o = (long)n * Kdst + dst;
   dW[o] = accumulate ? dW[o] + s : s;
 }
-// the same with four consecutive k per thread (K % 4 == 0, Cin % 4 == 0 for convolutions, P 16-byte aligned): the slab
-// reads are one dwordx4 per lane and split, a quarter of the load instructions (the sums run in the same z order: same bits)
-__global__ void wgrad_reduce4_kernel(const float* __restrict__ P, float* __restrict__ dW, int splits, int N, int K,
-                                     int Cin, int taps, int Kdst, int accumulate) {
-  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// Four consecutive k per thread (K % 4 == 0, Cin % 4 == 0 for convolutions, P 16-byte aligned) and the split loop dealt over
+// 8 lanes of the workgroup: thread (quad q = tid & 31, lane l = tid >> 5) adds the slabs l, l + 8, ... (one dwordx4 each),
+// the 8 lane sums are added in lane order through LDS.  A fixed order (deterministic); the dependent chain per output is
+// splits / 8 loads long instead of `splits` -- the kernel was bound by that chain (23 us for 93 launches per step).
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restrict__ P, float* __restrict__ dW, int splits, int N, int K,
+                                                             int Cin, int taps, int Kdst, int accumulate) {
+  __shared__ float4 sh[8 * 32];
+  const int ql = threadIdx.x & 31, l = threadIdx.x >> 5;
   const long total = (long)N * K;
-  const long idx = q * 4;
-  if (idx >= total) return;
-  const int n = (int)(idx / K), k = (int)(idx - (long)n * K);
+  const long idx = ((long)blockIdx.x * 32 + ql) * 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int zz = 0; zz < splits; ++zz) {
-    const float4 v = *reinterpret_cast<const float4*>(P + (long)zz * total + idx);
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-  }
+  if (idx < total)
+    for (int zz = l; zz < splits; zz += 8) {
+      const float4 v = *reinterpret_cast<const float4*>(P + (long)zz * total + idx);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  sh[l * 32 + ql] = s;
+  __syncthreads();
+  if (l != 0 || idx >= total) return;
+  for (int j = 1; j < 8; ++j) { const float4 v = sh[j * 32 + ql]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+  const int n = (int)(idx / K), k = (int)(idx - (long)n * K);
   const float sv[4] = {s.x, s.y, s.z, s.w};
   if (taps > 1) {
     const int tap = k / Cin, c = k - tap * Cin;   // c .. c + 3 stay inside the tap (Cin % 4 == 0)
@@ -944,7 +951,7 @@ extern "C" int stil_wgrad_tn(const float* dY, const float* X, float* dW, int M, 
   long total = (long)N * K;
   int taps = KH * KW;
   if (K % 4 == 0 && (taps == 1 || srcC % 4 == 0) && ((uintptr_t)workspace % 16) == 0)
-    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(cdiv(total / 4, 256)), dim3(256), 0, s, workspace, dW, splits, N, K, srcC,
+    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(cdiv(total / 4, 32)), dim3(256), 0, s, workspace, dW, splits, N, K, srcC,
                        taps, Kdst, accumulate);
   else
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, workspace, dW, splits, N, K, srcC,
