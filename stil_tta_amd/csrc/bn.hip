@@ -246,6 +246,45 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
   coef[2 * C + c] = s2 * invM;
 }
 
+// The same over 32 lanes x 8 column quads per workgroup (C % 4 == 0): one dwordx4 per lane and chunk, a dependent chain of
+// nch / 32 loads instead of nch / 8 (the kernel is that chain: 25 us alone, 110-160 us beside the other stream's GEMMs, on
+// the main stream of every BatchNorm backward).  Lane sums are added in lane order: deterministic.
+__global__ __launch_bounds__(256) void bn_bwd_final4_kernel(const float* __restrict__ part, int nch, int M, int C,
+                                     const float* __restrict__ gamma, const float* __restrict__ stats,
+                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef,
+                                     int accumulate) {
+  __shared__ float4 sh[2 * 32 * 8];
+  const int cq = threadIdx.x & 7, lane = threadIdx.x >> 3;
+  const int c = (blockIdx.x * 8 + cq) * 4;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  if (c < C)
+    for (int i = lane; i < nch; i += 32) {
+      const float4 u = *reinterpret_cast<const float4*>(part + (long)i * C + c);
+      const float4 v = *reinterpret_cast<const float4*>(part + (long)(nch + i) * C + c);
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+      b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+    }
+  sh[lane * 8 + cq] = a; sh[256 + lane * 8 + cq] = b;
+  __syncthreads();
+  if (lane != 0 || c >= C) return;
+  for (int l = 1; l < 32; ++l) {
+    const float4 u = sh[l * 8 + cq], v = sh[256 + l * 8 + cq];
+    a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+    b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+  }
+  const float s1[4] = {a.x, a.y, a.z, a.w}, s2[4] = {b.x, b.y, b.z, b.w};
+  const float invM = 1.f / (float)M;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int cc = c + j;
+    if (dbeta) dbeta[cc] = accumulate ? dbeta[cc] + s1[j] : s1[j];
+    if (dgamma) dgamma[cc] = accumulate ? dgamma[cc] + s2[j] : s2[j];
+    coef[cc] = gamma[cc] * stats[C + cc];
+    coef[C + cc] = s1[j] * invM;
+    coef[2 * C + cc] = s2[j] * invM;
+  }
+}
+
 // dx = gamma*rstd * (g - dbeta/M - xhat*dgamma/M)
 __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict__ dz, const float* __restrict__ z,
                                                          const float* __restrict__ x, const float* __restrict__ stats,
@@ -491,8 +530,12 @@ extern "C" int stil_bn_train_bwd(const float* dz, const float* z, const float* x
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(C / ct, nch), dim3(256), 0, s, dz, z, x, stats, gout, workspace, M, C,
                      ct, rpc, relu);
   STIL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 32)), dim3(256), 0, s, workspace, nch, M, C, gamma, stats, dgamma,
-                     dbeta, coef, accumulate);
+  if (C % 4 == 0 && ((uintptr_t)workspace % 16) == 0)
+    hipLaunchKernelGGL(bn_bwd_final4_kernel, dim3(cdiv(C, 32)), dim3(256), 0, s, workspace, nch, M, C, gamma, stats, dgamma,
+                       dbeta, coef, accumulate);
+  else
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 32)), dim3(256), 0, s, workspace, nch, M, C, gamma, stats, dgamma,
+                       dbeta, coef, accumulate);
   STIL_LAUNCH_CHECK();
   long total4 = (long)M * C / 4;
   int grid = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
