@@ -1,6 +1,5 @@
-"""Which ATen kernels does one training step still launch, and from which line of the package?  (GPU box)
-usage: python tests/tools/aten_ops.py [batch] [img]   -> table of aten ops with a device kernel, grouped by the innermost
-stil_tta_amd frame of their Python stack."""
+"""Which ATen ops (device kernels AND device-to-device memcpys) does one training step still issue, and from which line of the
+package?  (GPU box)  usage: python tests/tools/aten_ops.py [batch] [img]"""
 import collections, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -21,23 +20,26 @@ batch = synthetic_batch(fl, 286, B, P, seed=1, device="cuda")
 for _ in range(3):
     train_step(m, opt, batch)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     train_step(m, opt, batch)
     torch.cuda.synchronize()
 agg = collections.defaultdict(lambda: [0, 0.0])
+names = collections.Counter()
 for ev in prof.events():
-    if not ev.name.startswith("aten::") or ev.device_time_total <= 0 or not ev.kernels:
+    names[ev.name] += 1
+    if not ev.name.startswith("aten::") or ev.device_time_total <= 0:
         continue
+    if ev.cpu_children and any(c.name.startswith("aten::") and c.device_time_total > 0 for c in ev.cpu_children):
+        continue   # count the innermost op only
     frame = "?"
     for fr in (ev.stack or []):
-        if "stil_tta_amd" in fr and "site-packages" not in fr:
-            frame = fr.split("stil_tta_amd/")[-1]
+        if "stil_tta_amd/" in fr:
+            frame = fr.split("stil_tta_amd/")[-1].strip()
             break
-    k = (ev.name, frame)
+    kinds = ",".join(sorted({k.name[:28] for k in ev.kernels})) if ev.kernels else "-"
+    k = (ev.name, frame, kinds, str(ev.input_shapes)[:60])
     agg[k][0] += 1
-    agg[k][1] += sum(kk.duration for kk in ev.kernels)
-tot = 0
-for (name, frame), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
-    print(f"{n:5d} x {name:28s} {us:9.1f} us   {frame}")
-    tot += n
-print("total ATen ops with a device kernel:", tot)
+    agg[k][1] += ev.device_time_total
+for (name, frame, kinds, shp), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:45]:
+    print(f"{n:5d} x {name:22s} {us:8.1f} us  {kinds:30s} {frame[:60]:60s} {shp}")
+print("memcpy-like events:", {k: v for k, v in names.items() if "emcpy" in k or "copyBuffer" in k})
