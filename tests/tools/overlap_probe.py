@@ -1,6 +1,8 @@
 """Do an MFMA-bound GEMM and an HBM-bound streaming pass overlap when they run on two streams?  (GPU box)
 Times, per pair: GEMM alone, stream pass alone, both launched together (GEMM on one stream, the pass on another), for a
-few sizes of the streaming pass.  perfect overlap -> t_both ~ max; none -> t_both ~ sum."""
+few sizes of the streaming pass.  perfect overlap -> t_both ~ max; none -> t_both ~ sum.
+The second part needs tests/tools/libstream_probe.so (a probe kernel with a chosen grid / loads in flight; build it in the
+build container: hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o tests/tools/libstream_probe.so tests/tools/stream_probe.hip)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
