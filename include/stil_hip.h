@@ -99,6 +99,9 @@ int stil_transpose(const float* in, float* out, int R, int C, void* stream);
 /* ---- BatchNorm2d (NHWC rows), ReLU, residual, max-pool: models/resnets.py:112-132,248-252 ----
  * stats: [4,C] = mean, rstd, a=gamma*rstd, beta (z = (x-mean)*a + beta); bn_eval_affine's ab: [3,C] = a, beta, running_mean.  Train forward also updates the running
  * statistics (momentum, unbiased variance) and num_batches_tracked. z = relu?(x*a + b + resid).
+ * `resid_stats` (optional, stil_bn_train_fwd_tiles): `resid` is the RAW conv output of the block's shortcut and resid_stats its
+ * statistics block [4][C]; the shortcut's BatchNorm is applied inside this pass (the downsample branch never materialises its
+ * normalised output, models/resnets.py:126-129).
  * stil_bn_train_fwd_tiles with z == NULL computes the statistics only (running buffers, `stats`): the consumer applies
  * them while it stages its operand (stil_gemm_nt a_bn / stil_wgrad_tn x_bn).
  * bn_train_bwd's relu: 0 = none, 1 = mask (z > 0) read from z, 2 = mask recomputed from x and stats (only without
@@ -110,8 +113,8 @@ int stil_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
                       size_t workspace_bytes, void* stream);
 int stil_bn_train_fwd_tiles(const float* x, const float* tilestats, int tile_rows, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, long long* num_batches_tracked,
-                            const float* resid, float* z, float* stats, int M, int C, int relu, float eps,
-                            float momentum, void* workspace, size_t workspace_bytes, void* stream);
+                            const float* resid, const float* resid_stats, float* z, float* stats, int M, int C, int relu,
+                            float eps, float momentum, void* workspace, size_t workspace_bytes, void* stream);
 size_t stil_bn_tiles_workspace_bytes(int M, int C, int tile_rows);
 int stil_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float* ab, int C, float eps, void* stream);

@@ -158,10 +158,12 @@ __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const flo
   ab[c] = a; ab[C + c] = beta[c]; ab[2 * C + c] = rmean[c];
 }
 
-// z = relu?( (x - mean)*a + beta (+ resid) )
+// z = relu?( (x - mean)*a + beta (+ resid) );  rstats (optional): resid is the RAW output of the shortcut's conv and rstats that
+// layer's statistics block -- its BatchNorm (no ReLU) is applied here, (resid - rmean)*ra + rbeta, exactly as its own apply pass
+// would have (models/resnets.py:126-129: identity = self.downsample(x); out += identity)
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
-                                                        const float* __restrict__ resid, float* __restrict__ z,
-                                                        long total4, int C, int relu) {
+                                                        const float* __restrict__ resid, const float* __restrict__ rstats,
+                                                        float* __restrict__ z, long total4, int C, int relu) {
   const float* A = stats + 2 * C;
   const float* B = stats + 3 * C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
@@ -172,7 +174,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     const float4 mu = *reinterpret_cast<const float4*>(stats + c);
     v.x = (v.x - mu.x) * a.x + b.x; v.y = (v.y - mu.y) * a.y + b.y; v.z = (v.z - mu.z) * a.z + b.z; v.w = (v.w - mu.w) * a.w + b.w;
     if (resid) {
-      const float4 r = reinterpret_cast<const float4*>(resid)[i];
+      float4 r = reinterpret_cast<const float4*>(resid)[i];
+      if (rstats) {
+        const float4 rm = *reinterpret_cast<const float4*>(rstats + c);
+        const float4 ra = *reinterpret_cast<const float4*>(rstats + 2 * C + c);
+        const float4 rb = *reinterpret_cast<const float4*>(rstats + 3 * C + c);
+        r.x = (r.x - rm.x) * ra.x + rb.x; r.y = (r.y - rm.y) * ra.y + rb.y; r.z = (r.z - rm.z) * ra.z + rb.z; r.w = (r.w - rm.w) * ra.w + rb.w;
+      }
       v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
     }
     if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -467,7 +475,7 @@ extern "C" int stil_bn_train_fwd(const float* x, const float* gamma, const float
   STIL_LAUNCH_CHECK();
   long total4 = (long)M * C / 4;
   int grid = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, s, x, stats, resid, z, total4, C, relu);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, s, x, stats, resid, (const float*)nullptr, z, total4, C, relu);
   STIL_LAUNCH_CHECK();
   return STIL_OK;
 }
@@ -489,8 +497,8 @@ extern "C" size_t stil_bn_tiles_workspace_bytes(int M, int C, int tile_rows) {
 }
 extern "C" int stil_bn_train_fwd_tiles(const float* x, const float* tilestats, int tile_rows, const float* gamma, const float* beta,
                                        float* running_mean, float* running_var, long long* num_batches_tracked,
-                                       const float* resid, float* z, float* stats, int M, int C, int relu, float eps,
-                                       float momentum, void* workspace, size_t workspace_bytes, void* stream) {
+                                       const float* resid, const float* resid_stats, float* z, float* stats, int M, int C, int relu,
+                                       float eps, float momentum, void* workspace, size_t workspace_bytes, void* stream) {
   STIL_REQUIRE(x && tilestats && gamma && beta && stats && workspace, "stil_bn_train_fwd_tiles: null pointer");
   STIL_REQUIRE(z || !resid, "stil_bn_train_fwd_tiles: statistics-only call (z == NULL) cannot take a residual");
   STIL_REQUIRE(tile_rows > 0 && M > 0 && C % 4 == 0, "stil_bn_train_fwd_tiles: bad shape M=%d C=%d tile_rows=%d", M, C, tile_rows);
@@ -507,7 +515,8 @@ extern "C" int stil_bn_train_fwd_tiles(const float* x, const float* tilestats, i
   if (!z) return STIL_OK;   // statistics only: the consumer applies them while it stages its operand
   long total4 = (long)M * C / 4;
   int grid = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, s, x, stats, resid, z, total4, C, relu);
+  STIL_REQUIRE(!resid_stats || resid, "stil_bn_train_fwd_tiles: resid_stats without resid");
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, s, x, stats, resid, resid_stats, z, total4, C, relu);
   STIL_LAUNCH_CHECK();
   return STIL_OK;
 }

@@ -57,7 +57,7 @@ def set_teacher_pipe(pipe: Optional[TeacherPipe]):
 
 
 def _conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool, train: bool, resid=None, stem=None, passthrough=False, defer=False,
-             xstats=None, premask_in=None, premask_out=None):
+             xstats=None, premask_in=None, premask_out=None, rstats=None):
     """passthrough (first conv of a residual block): -> (out, alias of x) so the identity branch's gradient is folded
     into this conv's input-gradient GEMM (ops.ConvBnActFn).
     defer (training, inner layers of a block): -> (..., stats) with out = the RAW conv output; the next conv gets them as
@@ -68,11 +68,11 @@ def _conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool, train: bool, re
     if train:
         out = ops.ConvBnActFn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                     bn.num_batches_tracked, resid, k, stride, pad, relu, stem, passthrough, defer, xstats,
-                                    premask_in, premask_out)
+                                    premask_in, premask_out, rstats)
         if pipe is not None:
             pipe.published()
         return out
-    assert not defer and xstats is None
+    assert not defer and xstats is None and rstats is None
     if pipe is not None:
         pipe.before_teacher_bn(bn)
     out = ops.conv_bn_eval(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, resid, k, stride, pad,
@@ -108,10 +108,14 @@ class Bottleneck(nn.Module):  # models/resnets.py:91-132
             out, st2 = _conv_bn(out, self.conv2, self.bn2, True, train, defer=True, xstats=st1)
         else:
             out = _conv_bn(out, self.conv2, self.bn2, True, train, xstats=st1)
+        rst = None
         if self.downsample is not None:
-            identity = _conv_bn(identity, self.downsample[0], self.downsample[1], False, train)
+            if train and ops.can_defer_bn(self.downsample[0].out_channels):   # the shortcut's BatchNorm is applied inside bn3's pass
+                identity, rst = _conv_bn(identity, self.downsample[0], self.downsample[1], False, train, defer=True)
+            else:
+                identity = _conv_bn(identity, self.downsample[0], self.downsample[1], False, train)
         Nb, H, W, C = identity.shape
-        out = _conv_bn(out, self.conv3, self.bn3, True, train, resid=identity.reshape(Nb * H * W, C), xstats=st2, premask_out=cout)
+        out = _conv_bn(out, self.conv3, self.bn3, True, train, resid=identity.reshape(Nb * H * W, C), xstats=st2, premask_out=cout, rstats=rst)
         if cout is not None:
             out._stil_premask = cout   # the next block's first conv (the only consumer of `out`) picks it up
         return out
@@ -137,10 +141,14 @@ class BasicBlock(nn.Module):  # models/resnets.py:50-88
             out, identity, st1 = _conv_bn(x, self.conv1, self.bn1, True, train, passthrough=True, defer=True, premask_in=cin)
         else:
             out, identity = _conv_bn(x, self.conv1, self.bn1, True, train, passthrough=True, premask_in=cin)
+        rst = None
         if self.downsample is not None:
-            identity = _conv_bn(identity, self.downsample[0], self.downsample[1], False, train)
+            if train and ops.can_defer_bn(self.downsample[0].out_channels):
+                identity, rst = _conv_bn(identity, self.downsample[0], self.downsample[1], False, train, defer=True)
+            else:
+                identity = _conv_bn(identity, self.downsample[0], self.downsample[1], False, train)
         Nb, H, W, C = identity.shape
-        out = _conv_bn(out, self.conv2, self.bn2, True, train, resid=identity.reshape(Nb * H * W, C), xstats=st1, premask_out=cout)
+        out = _conv_bn(out, self.conv2, self.bn2, True, train, resid=identity.reshape(Nb * H * W, C), xstats=st1, premask_out=cout, rstats=rst)
         if cout is not None:
             out._stil_premask = cout
         return out

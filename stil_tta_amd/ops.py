@@ -341,7 +341,7 @@ class ConvBnActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, gamma, beta, rmean, rvar, nbt, resid, k, stride, pad, relu, stem, passthrough=False, defer=False, xstats=None,
-                premask_in=None, premask_out=None):
+                premask_in=None, premask_out=None, rstats=None):
         """passthrough: also return x itself as a second output.  A residual block routes its identity branch through
         that alias, so the branch's gradient arrives HERE and is added inside the input-gradient GEMM's epilogue
         instead of by a separate accumulation kernel of the autograd engine.
@@ -358,7 +358,9 @@ class ConvBnActFn(torch.autograd.Function):
         reads z nor materialises the masked gradient for the identity branch (one wide-tensor pass fewer per block)."""
         _chk(x, w, gamma, beta, resid)
         ctx.set_materialize_grads(False)
-        assert not defer or (relu and resid is None), "only conv+BN+ReLU layers without a residual can defer their BatchNorm"
+        # deferred layers: the inner conv+BN+ReLU of a block (applied by the next conv's operand staging) and the shortcut's
+        # conv+BN (no ReLU; applied inside the block's final BatchNorm pass, `rstats` there)
+        assert not defer or resid is None, "a layer with a residual input cannot defer its BatchNorm"
         Cout = w.shape[0]
         dev = x.device
         fused = _BN_EPILOGUE_STATS and Cout % 4 == 0
@@ -393,9 +395,10 @@ class ConvBnActFn(torch.autograd.Function):
         if fused:
             nb = lib().bn_tiles_workspace_bytes(M, Cout, tile_rows)
             ws = _ws.get(nb, dev)
-            lib().bn_train_fwd_tiles(_p(y), _p(ts), tile_rows, _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(nbt), _p(resid), _p(z),
+            lib().bn_train_fwd_tiles(_p(y), _p(ts), tile_rows, _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(nbt), _p(resid), _p(rstats), _p(z),
                                      _p(stats), M, Cout, 1 if relu else 0, 1e-5, 0.1, _p(ws), nb, _stream())
         else:
+            assert rstats is None
             nb = lib().bn_workspace_bytes(M, Cout)
             ws = _ws.get(nb, dev)
             lib().bn_train_fwd(_p(y), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(nbt), _p(resid), _p(z), _p(stats), M, Cout,
@@ -476,7 +479,7 @@ class ConvBnActFn(torch.autograd.Function):
             gw = geom[:9]
             dw = wgrad_param(w, dy, x, M, Cout, k * k * Cin, geom=gw, x_bn=xstats)
         return (dx, dw, (None if gslot is not None else dgamma), (None if bslot is not None else dbeta), None, None, None,
-                dres, None, None, None, None, None, None, None, None, None, None)
+                dres, None, None, None, None, None, None, None, None, None, None, None)
 
 
 def strided_dgrad(dy, w, Nb, H, W_, Cin, OH, OW, Cout, k, stride, pad):

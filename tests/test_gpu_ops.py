@@ -688,7 +688,7 @@ def test_bn_statistics_two_pass_and_tile_paths_agree_with_float64(ops, M, C, til
             nb = L.bn_tiles_workspace_bytes(M, C, T)
             ws = torch.empty(max(nb, 8), dtype=torch.uint8, device="cuda")
             L.bn_train_fwd_tiles(y.data_ptr(), ts.data_ptr(), T, gd.data_ptr(), bd.data_ptr(), rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(),
-                                 None, z.data_ptr(), stats.data_ptr(), M, C, 0, 1e-5, 0.1, ws.data_ptr(), nb, None)
+                                 None, None, z.data_ptr(), stats.data_ptr(), M, C, 0, 1e-5, 0.1, ws.data_ptr(), nb, None)
         else:
             y = ops.gemm_nt(Ad, Wd, M, C, K)
             nb = L.bn_workspace_bytes(M, C)
