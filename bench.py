@@ -71,6 +71,10 @@ def parse():
                     help="device: additionally measure the device input pipeline (augment.ContrastiveBatchBuilder on a uint8 shard resident "
                          "in HBM: crop / flip / jitter / gray / blur + tabular corruption) alone and inside the training loop; printed as a "
                          "SEPARATE JSON line before the contract line, never `value`")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="deadline (s) of the N-rank launch and of every collective's "
+                    "process-group timeout: ranks still running then are terminated, their stderr tails forwarded, exit code 124")
+    ap.add_argument("--launch-fault", default="", help="TEST ONLY, with --launch-check: 'raise:R' makes rank R raise after the rendezvous, "
+                    "'sleep:R' makes rank R sleep past any deadline")
     ap.add_argument("--launch-check", action="store_true", help="exercise only the N-rank launch, rendezvous, barrier and max-over-ranks "
                     "timing protocol with an EMPTY step (no GPU, no model): the CPU test of the launcher; value is null")
     return ap.parse_args()
@@ -135,21 +139,28 @@ def pipeline_measure(a, m, opt, dev, fl, train_step, rank, world):
 
 def launch_ranks(a) -> int:
     """`--gpus N` outside torch.distributed.run: N fresh rank processes, started BEFORE this process has made any GPU call
-    (a process that has initialised the GPU is never re-executed or forked).  Rank r gets LOCAL_RANK = r -> GPU r."""
+    (a process that has initialised the GPU is never re-executed or forked).  Rank r gets LOCAL_RANK = r -> GPU r.
+    The launch has a deadline (`--launch-timeout`, default 1500 s): ranks still running then are terminated (they are
+    fresh children, never an exec of a GPU process), every rank's stderr tail is forwarded with the named cause, exit code 124.
+    A rank that exits non-zero ends the job at once with its code (the others would wait for it in a collective)."""
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
+    procs, logs = [], []
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
         env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or a.gpus) // a.gpus)))   # as torch.distributed.run: no N-fold host oversubscription
+        log = tempfile.TemporaryFile(mode="w+")              # each rank's stderr: forwarded as a tail when the job fails
+        logs.append(log)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))   # rank 0 prints the line
-    rc = 0
+                                      stdout=None if r == 0 else subprocess.DEVNULL, stderr=log))   # rank 0 prints the line
+    rc, cause = 0, None
+    deadline = time.monotonic() + a.launch_timeout
     try:
         pending = list(procs)
         while pending:
@@ -159,22 +170,62 @@ def launch_ranks(a) -> int:
                     continue
                 pending.remove(p)
                 if c != 0 and rc == 0:
-                    rc = c
+                    rc, cause = c, f"rank {procs.index(p)} exited with code {c}"
                     for q in pending:      # one rank failed: the others would wait in a collective forever
                         q.terminate()
+            if pending and rc == 0 and time.monotonic() > deadline:
+                rc = 124
+                cause = (f"launch deadline of {a.launch_timeout:.0f} s passed with rank(s) "
+                         f"{[procs.index(q) for q in pending]} still running: terminated")
+                for q in pending:
+                    q.terminate()
             time.sleep(0.05)
     finally:
+        t_kill = time.monotonic() + 10
         for p in procs:
+            while p.poll() is None and time.monotonic() < t_kill:
+                time.sleep(0.05)
             if p.poll() is None:
                 p.kill()
+    for r, log in enumerate(logs):
+        log.seek(0)
+        txt = log.read()
+        log.close()
+        if rc != 0:
+            print(f"---- rank {r} (exit {procs[r].poll()}) stderr tail ----\n{txt[-2500:]}", file=sys.stderr)
+        elif r == 0 and txt:
+            sys.stderr.write(txt)       # a healthy job: rank 0's notes only
+    if rc != 0:
+        print(f"bench.py launcher: FAILED -- {cause}", file=sys.stderr, flush=True)
     return rc
+
+
+def check_devices(world: int, backend: str, device_count: int) -> bool:
+    """One GPU per rank.  Under RCCL ("nccl") fewer devices than ranks is an error named here, before the rendezvous
+    (RCCL would refuse two ranks on one device much later, with an opaque message).  Under gloo ranks MAY share a device
+    (the one-GPU test box): returns True then, and the bench prints `roofline: null` -- HIP events around a launch then also
+    span the other process's time slices and price nothing."""
+    if device_count >= world:
+        return False
+    if backend == "nccl":
+        raise SystemExit(f"bench.py: --gpus {world} needs {world} visible GPUs for the RCCL backend, found {device_count} "
+                         f"(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?); one process per GPU, ranks never share a device")
+    return True
 
 
 def launch_check(a):
     """The bench protocol with an empty step: rendezvous (gloo), barrier, K timed no-op steps, barrier, MAX over ranks, rank 0
     prints the line.  No GPU and no model: what it checks is that `--gpus N` really yields an N-rank job."""
     from stil_tta_amd.driver import init_distributed
-    rank, world, local = init_distributed(backend="gloo")
+    if os.environ.get("STIL_FAKE_DEVICE_COUNT"):     # TEST ONLY: the "too few devices" refusal without a GPU
+        check_devices(int(os.environ.get("WORLD_SIZE", "1")), os.environ.get("STIL_DIST_BACKEND") or "nccl", int(os.environ["STIL_FAKE_DEVICE_COUNT"]))
+    rank, world, local = init_distributed(backend="gloo", timeout_s=a.launch_timeout)
+    kind, _, who = a.launch_fault.partition(":")
+    if kind and int(who or -1) == rank:
+        if kind == "raise":
+            raise RuntimeError(f"injected failure on rank {rank} (--launch-fault)")
+        if kind == "sleep":
+            time.sleep(3600)
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
@@ -183,15 +234,24 @@ def launch_check(a):
     if world > 1:
         dist.barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    per_rank = gather_times(t, world)
     if rank == 0:
         print(json.dumps(dict(metric="training samples/sec (labeled+unlabeled) for DVM STiL", value=None, unit="samples/s", n_gpus=world,
                               steps=a.steps, warmup=a.warmup, launch_check=True, local_ranks=sorted({local}),
+                              ms_per_step_by_rank=[round(x / max(1, a.steps) * 1e3, 4) for x in per_rank],
                               config=dict(global_batch=a.batch * world, parallelism=f"dp{world}"))), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def gather_times(t, world):
+    """Every rank's time of the timed region (the contract's ms_per_step is their MAX; the list makes a straggler visible)."""
+    if world == 1:
+        return [float(t.item())]
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]
 
 
 def cpu_baseline(field_lengths, classes, img, batch, steps=3):
@@ -225,11 +285,15 @@ def main():
     from stil_tta_amd.driver import init_distributed, train_step, synthetic_batch
     from stil_tta_amd.flat import StilAdam
 
-    rank, world, local = init_distributed()
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    backend = os.environ.get("STIL_DIST_BACKEND") or "nccl"
+    ndev = torch.cuda.device_count()      # counting devices does not initialise the GPU
+    assert ndev > 0 and torch.cuda.is_available(), "bench.py needs a GPU (no CPU path in the product)"
+    shared_device = check_devices(world_env, backend, ndev) if world_env > 1 else False
+    rank, world, local = init_distributed(timeout_s=a.launch_timeout)
     if world != a.gpus and rank == 0:
         print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: following the launcher's environment", file=sys.stderr)
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path in the product)"
-    local = local % max(1, torch.cuda.device_count())
+    local = local % ndev if shared_device else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     extra = {}
@@ -288,22 +352,23 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    per_rank = gather_times(torch.tensor([dt], dtype=torch.float64, device=dev), world)
+    dt = max(per_rank)            # the contract: MAX over ranks
     # OUTSIDE the timed region, two more steps.  (1) the step as timed (both streams), HIP events around the GEMM launches on
     # whichever stream they go to: the kernel while the side stream co-runs (`two_stream`).  (2) every launch kept on ONE
     # stream and bracketed by HIP events: clean per-kernel durations (no second kernel sharing the chip), which is what
     # the roofline of the kernel is priced on.
-    if not a.graph:
-        L.begin_profile(single_stream=False, only=("gemm_nt",))
-        train_step(m, opt, batch)
-        prof_conc = L.end_profile()
-    L.begin_profile(only=None if a.breakdown else ("gemm_nt", "wgrad_tn"))
-    (eager_step if a.graph else train_step)(m, opt, batch)
-    torch.cuda.synchronize()
-    prof = L.end_profile()
+    # Ranks that share a device (gloo on the one-GPU test box) skip both: an event pair then also spans the OTHER process's
+    # time slices, so it prices nothing (`roofline: null` with the reason).
+    if not shared_device:
+        if not a.graph:
+            L.begin_profile(single_stream=False, only=("gemm_nt",))
+            train_step(m, opt, batch)
+            prof_conc = L.end_profile()
+        L.begin_profile(only=None if a.breakdown else ("gemm_nt", "wgrad_tn"))
+        (eager_step if a.graph else train_step)(m, opt, batch)
+        torch.cuda.synchronize()
+        prof = L.end_profile()
     loss = float(m.last["loss"].detach())
     assert loss == loss, "loss is NaN"
     if a.pipeline == "device" and a.variant in ("dvm", "saint", "cardiac"):
@@ -316,52 +381,57 @@ def main():
         # dominant kernel = the gemm_nt instantiation with the largest share of the step's GPU time; meta[0] is the
         # configuration the library reports for that very launch (stil_gemm_nt_config: tile, BK, vector loads, two-level sums)
         byvar = {}
-        for name, ms, meta in prof:
+        for name, ms, meta in prof or ():
             if name == "gemm_nt" and meta:
                 c = byvar.setdefault(meta[0], [0, 0.0, 0.0, 0.0])
                 c[0] += 1; c[1] += ms * 1e-3; c[2] += meta[1]; c[3] += meta[3]
-        var, (nl, tsum, fsum, bsum) = max(byvar.items(), key=lambda kv: kv[1][1])
-        kname = kernel_name(var)
-        achieved = fsum / tsum / 1e12 if tsum > 0 else 0.0
-        roof = dict(bound="mfma", kernel=kname, achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS,
-                    unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
-                    launches_per_step=nl, avg_launch_us=round(tsum / max(1, nl) * 1e6, 2),
-                    flops_per_step=fsum, share_of_step_time=round(tsum / (dt / a.steps), 4),
-                    algorithmic_bytes=round(bsum / max(1, nl)),
-                    all_gemm_nt={kernel_name(k): dict(launches=v[0], ms=round(v[1] * 1e3, 3), tflops=round(v[2] / v[1] / 1e12, 2)) for k, v in
-                                 sorted(byvar.items(), key=lambda kv: -kv[1][1])},
-                    note="achieved / avg_launch_us: HIP events around every launch of one extra step run right after the timed region "
-                         "with all launches on ONE stream (agrees with profiles/*_single_stream.csv = this command with "
-                         "STIL_WGRAD_STREAM=0); two_stream: the same kernel during another extra step, while the side stream (EMA "
-                         "teacher, weight gradients) co-runs -- what a rocprofv3 trace of the default command averages "
-                         "(profiles/*_bench_kernel_stats.csv)")
-        # HBM traffic of that kernel: PMC counters cannot be read from inside the process; the latest separate-pass
-        # rocprofv3 measurement of this same command is kept under profiles/ and quoted ONLY while it is for this kernel AND was
-        # taken on these very kernel sources (kernel_source_sha = content hash of csrc/: the box has no .git to ask).
-        try:
-            from stil_tta_amd._lib import source_hash
-            sha = source_hash()
-            pdir = os.path.join(ROOT, "profiles")
-            pmc = sorted(f for f in os.listdir(pdir) if f.endswith("pmc_traffic.json"))
-            tj = json.load(open(os.path.join(pdir, pmc[-1]))) if pmc else None
-            if tj and tj["kernel"] == kname and tj.get("kernel_source_sha") == sha and a.batch == 256 and a.img == 224:
-                roof["traffic"] = round(tj["bytes_per_launch"])
-                roof["traffic_source"] = f"profiles/{pmc[-1]} (kernel sources {sha})"
-            mu = sorted(f for f in os.listdir(pdir) if f.endswith("mfma_util.json"))
-            uj = json.load(open(os.path.join(pdir, mu[-1]))) if mu else None
-            if uj and kname in uj.get("kernels", {}) and uj.get("kernel_source_sha") == sha and a.batch == 256 and a.img == 224:
-                roof["mfma_busy"] = uj["kernels"][kname]["mfma_busy_of_cu_busy"]
-                roof["mfma_busy_source"] = (f"profiles/{mu[-1]} (kernel sources {sha}; SQ_VALU_MFMA_BUSY_CYCLES / 4 / SQ_BUSY_CU_CYCLES, "
-                                            "rocprofv3 --pmc on this command)")
-        except Exception:
-            pass
-        if prof_conc:  # the same kernel while the second stream co-runs (what a rocprofv3 trace of this command averages)
-            cn, ct, cf = 0, 0.0, 0.0
-            for name, ms, meta in prof_conc:
-                if name == "gemm_nt" and meta and meta[0] == var:
-                    cn += 1; ct += ms * 1e-3; cf += meta[1]
-            if cn:
-                roof["two_stream"] = dict(avg_launch_us=round(ct / cn * 1e6, 2), achieved=round(cf / ct / 1e12, 2), launches=cn)
+        roof = None
+        roof_reason = ("ranks share a device (gloo backend, fewer GPUs than ranks): HIP events around a launch also span the other "
+                       "process's time slices" if shared_device else "no gemm_nt launch was recorded")
+        if byvar:
+            var, (nl, tsum, fsum, bsum) = max(byvar.items(), key=lambda kv: kv[1][1])
+            assert tsum > 0 and fsum > 0, (var, nl, tsum, fsum)
+            kname = kernel_name(var)
+            achieved = fsum / tsum / 1e12
+            roof = dict(bound="mfma", kernel=kname, achieved=float(f"{achieved:.6g}"), peak=PEAK_FP32_MFMA_TFLOPS,
+                        unit="TFLOP/s", frac=float(f"{achieved / PEAK_FP32_MFMA_TFLOPS:.6g}"), traffic=None,
+                        launches_per_step=nl, avg_launch_us=round(tsum / max(1, nl) * 1e6, 2),
+                        flops_per_step=fsum, share_of_step_time=round(tsum / (dt / a.steps), 4),
+                        algorithmic_bytes=round(bsum / max(1, nl)),
+                        all_gemm_nt={kernel_name(k): dict(launches=v[0], ms=round(v[1] * 1e3, 3), tflops=round(v[2] / v[1] / 1e12, 2)) for k, v in
+                                     sorted(byvar.items(), key=lambda kv: -kv[1][1])},
+                        note="achieved / avg_launch_us: HIP events around every launch of one extra step run right after the timed region "
+                             "with all launches on ONE stream (agrees with profiles/*_single_stream.csv = this command with "
+                             "STIL_WGRAD_STREAM=0); two_stream: the same kernel during another extra step, while the side stream (EMA "
+                             "teacher, weight gradients) co-runs -- what a rocprofv3 trace of the default command averages "
+                             "(profiles/*_bench_kernel_stats.csv)")
+            # HBM traffic of that kernel: PMC counters cannot be read from inside the process; the latest separate-pass
+            # rocprofv3 measurement of this same command is kept under profiles/ and quoted ONLY while it is for this kernel AND was
+            # taken on these very kernel sources (kernel_source_sha = content hash of csrc/: the box has no .git to ask).
+            try:
+                from stil_tta_amd._lib import source_hash
+                sha = source_hash()
+                pdir = os.path.join(ROOT, "profiles")
+                pmc = sorted(f for f in os.listdir(pdir) if f.endswith("pmc_traffic.json"))
+                tj = json.load(open(os.path.join(pdir, pmc[-1]))) if pmc else None
+                if tj and tj["kernel"] == kname and tj.get("kernel_source_sha") == sha and a.batch == 256 and a.img == 224:
+                    roof["traffic"] = round(tj["bytes_per_launch"])
+                    roof["traffic_source"] = f"profiles/{pmc[-1]} (kernel sources {sha})"
+                mu = sorted(f for f in os.listdir(pdir) if f.endswith("mfma_util.json"))
+                uj = json.load(open(os.path.join(pdir, mu[-1]))) if mu else None
+                if uj and kname in uj.get("kernels", {}) and uj.get("kernel_source_sha") == sha and a.batch == 256 and a.img == 224:
+                    roof["mfma_busy"] = uj["kernels"][kname]["mfma_busy_of_cu_busy"]
+                    roof["mfma_busy_source"] = (f"profiles/{mu[-1]} (kernel sources {sha}; SQ_VALU_MFMA_BUSY_CYCLES / 4 / SQ_BUSY_CU_CYCLES, "
+                                                "rocprofv3 --pmc on this command)")
+            except Exception:
+                pass
+            if prof_conc:  # the same kernel while the second stream co-runs (what a rocprofv3 trace of this command averages)
+                cn, ct, cf = 0, 0.0, 0.0
+                for name, ms, meta in prof_conc:
+                    if name == "gemm_nt" and meta and meta[0] == var:
+                        cn += 1; ct += ms * 1e-3; cf += meta[1]
+                if cn:
+                    roof["two_stream"] = dict(avg_launch_us=round(ct / cn * 1e6, 2), achieved=round(cf / ct / 1e12, 2), launches=cn)
         fps = FLOPS_PER_SAMPLE.get((a.img, a.ncat + a.ncon))
         out = dict(metric="training samples/sec (labeled+unlabeled) for DVM STiL", value=round(value, 2), unit="samples/s",
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3),
@@ -372,14 +442,17 @@ def main():
                                global_batch=a.batch * world, parallelism=f"dp{world}", precision="fp32-exact MFMA",
                                launch="hipGraph replay" if a.graph else "eager",
                                input="host memory through data.DevicePrefetcher (PCIe-inclusive)" if a.host_input else "resident in HBM"),
+                   ms_per_step_by_rank=[round(x / a.steps * 1e3, 3) for x in per_rank],
                    roofline=roof, loss=round(loss, 5),
                    hbm_peak_gb=round(torch.cuda.max_memory_allocated(dev) / 1e9, 2), hbm_reserved_gb=round(torch.cuda.memory_reserved(dev) / 1e9, 2))
+        if roof is None:
+            out["roofline_reason"] = roof_reason
         if fps:
             out["step_tflops_algorithmic"] = round(value * fps / 1e12, 2)
             out["step_frac_of_fp32_mfma_peak"] = round(value * fps / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4)
         if a.breakdown:
             agg = {}
-            for name, ms, meta in prof:
+            for name, ms, meta in prof or ():
                 key = name if name != "gemm_nt" else kernel_name(meta[0])
                 c = agg.setdefault(key, [0, 0.0])
                 c[0] += 1; c[1] += ms
@@ -388,7 +461,7 @@ def main():
                 print(f"  {k:28s} {v[0]:5d} launches {v[1]:9.3f} ms {100 * v[1] / tot:5.1f}%", file=sys.stderr)
             print(f"  sum of C-ABI kernels {tot:.3f} ms of {dt / a.steps * 1e3:.3f} ms/step", file=sys.stderr)
             shapes = {}
-            for name, ms, meta in prof:
+            for name, ms, meta in prof or ():
                 if name in ("gemm_nt", "wgrad_tn") and meta:
                     c = shapes.setdefault(meta[2], [0, 0.0, 0.0])
                     c[0] += 1; c[1] += ms; c[2] += meta[1]

@@ -24,8 +24,11 @@ def anneal_lambda(warmup_epochs: int, max_epochs: int):
     return f
 
 
-def init_distributed(backend: Optional[str] = None):
-    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run). Returns (rank, world, local_rank)."""
+def init_distributed(backend: Optional[str] = None, timeout_s: Optional[float] = None):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run). Returns (rank, world, local_rank).
+    `timeout_s` (default STIL_DIST_TIMEOUT_S or 900): the process group's timeout -- a rank that never reaches the rendezvous
+    or a collective makes the others RAISE after that long instead of waiting for the job's outer limit.  Under the RCCL
+    backend every rank needs its own GPU: fewer visible devices than LOCAL_WORLD_SIZE is refused here by name."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -34,9 +37,19 @@ def init_distributed(backend: Optional[str] = None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:  # "nccl" is RCCL on ROCm; STIL_DIST_BACKEND=gloo lets several ranks share one GPU (tests)
             backend = os.environ.get("STIL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        if torch.cuda.is_available():
-            torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        ndev = torch.cuda.device_count()
+        if backend == "nccl":
+            need = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+            if ndev < need or local >= ndev:
+                raise RuntimeError(f"init_distributed: {need} local rank(s) on the RCCL backend need {need} visible GPUs, found {ndev} "
+                                   f"(LOCAL_RANK={local}); one process per GPU, ranks never share a device")
+            torch.cuda.set_device(local)
+        elif ndev > 0 and torch.cuda.is_available():
+            torch.cuda.set_device(local % ndev)        # gloo: the ranks of a test may share the one GPU of the box
+        import datetime
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("STIL_DIST_TIMEOUT_S", "900"))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
     return rank, world, local
 
 

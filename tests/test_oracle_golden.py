@@ -47,6 +47,30 @@ def test_oracle_matches_reference_golden(name):
             assert abs(float(v.sum()) - float(fx[key])) <= 2e-5 * (1.0 + ref_abs), key
 
 
+def test_oracle_trajectory_matches_reference_golden():
+    """Five consecutive optimisation steps of the oracle against the trajectory the REAL reference took
+    (tests/golden/traj_r18.npz, oracle/make_golden_traj.py): every loss term of every step, the logged ratios exactly, the
+    final state on the stored strided sample.  Oracle and reference share ATen's CPU kernels, so the bar is tight; the device
+    test (tests/test_gpu_step.py) uses the float64 yardsticks stored beside the reference's values."""
+    from oracle import make_golden_traj as T
+    fx = np.load(os.path.join(GOLD, "traj_r18.npz"))
+    hp, sd, batches, masks = T.build()
+    steps, state = T.run_oracle(hp, sd, batches, masks)
+    for s_ in range(T.STEPS):
+        for k, v in steps[s_].items():
+            if "ref_" + k not in fx.files:      # loss_pt is a local of the reference's step, not a logged scalar
+                continue
+            ref = float(fx["ref_" + k][s_])
+            assert abs(v - ref) <= (1e-6 if k.endswith("_ratio") else 2e-5 * (1 + abs(ref))), (s_, k, v, ref)
+    assert any(0 < r < 1 for r in fx["ref_mask1_ratio"])
+    for key in fx.files:
+        if key.startswith("state/") and state[key[6:]].is_floating_point():
+            got, ref = T.sample(state[key[6:]]).double().numpy(), fx[key].astype(np.float64)
+            err = np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30)
+            # a weight whose gradient is rounding noise moves +-lr per Adam step: thread-count-dependent reductions may flip it
+            assert err <= 3 * float(fx["dist64/" + key[6:]]) + 1e-4, (key, err)
+
+
 def test_epoch_end_commits_prototypes():
     hp = O.default_hparams(num_classes=3, projection_dim=4)
     sd = {"prototypes": torch.zeros(3, 4), "prototypes_sum": torch.arange(12.0).reshape(3, 4),
