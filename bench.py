@@ -154,7 +154,8 @@ def launch_ranks(a) -> int:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
-        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or a.gpus) // a.gpus)))   # as torch.distributed.run: no N-fold host oversubscription
+        from stil_tta_amd.driver import host_cpu_share
+        env.setdefault("OMP_NUM_THREADS", str(max(1, host_cpu_share() // a.gpus)))   # as torch.distributed.run: no N-fold host oversubscription
         log = tempfile.TemporaryFile(mode="w+")              # each rank's stderr: forwarded as a tail when the job fails
         logs.append(log)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
@@ -257,6 +258,8 @@ def gather_times(t, world):
 def cpu_baseline(field_lengths, classes, img, batch, steps=3):
     """The oracle's full step (training_step + backward + Adam) on the host cores: a bounded sample of the workload."""
     from oracle import stil_oracle as O
+    from stil_tta_amd.driver import host_cpu_share
+    torch.set_num_threads(host_cpu_share())     # this job's CPU share (cgroup quota), not the node's logical CPU count: 4.4x faster on the GPU box
     hp = O.default_hparams(field_lengths=field_lengths, num_classes=classes, img_size=img, batch_size=batch, start_epoch=0)
     sd = O.init_state(hp, seed=0)
     g = torch.Generator().manual_seed(1)
@@ -270,7 +273,8 @@ def cpu_baseline(field_lengths, classes, img, batch, steps=3):
     dt = (time.perf_counter() - t0) / steps
     return dict(value=round(batch / dt, 3), unit="samples/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"{steps} timed steps (1 warm-up) of batch {batch} at the workload's shapes "
-                       f"({img}px, {len(field_lengths)} columns, K={classes}); oracle/stil_oracle.py full_step, torch {torch.__version__} CPU",
+                       f"({img}px, {len(field_lengths)} columns, K={classes}); oracle/stil_oracle.py full_step, torch {torch.__version__} CPU, "
+                       f"threads = the job's CPU share (cgroup quota) of the box's {os.cpu_count()} logical CPUs",
                 s_per_step=round(dt, 3))
 
 

@@ -92,6 +92,15 @@ int stil_conv_weight_layout(const float* w, float* w_fwd, float* w_dgrad, int Co
 /* dgrad phase operand: w_sub[ci][ky'][kx'][co] = w[co][ci][ky0 + s*(KHs-1-ky')][kx0 + s*(KWs-1-kx')] */
 int stil_conv_weight_layout_phase(const float* w, float* w_sub, int Cout, int Cin, int KH, int KW, int stride,
                                   int ky0, int kx0, int KHs, int KWs, void* stream);
+/* Every per-step weight re-layout of a model in ONE launch (the three maps above: kind 0 = w_fwd, kind 1 = w_dgrad /
+ * transpose, kind 2 = dgrad phase).  jobs: device array of n records of stil_weight_layout_job_bytes() bytes
+ *   { int64 src, dst (float offsets into src_base / dst_base); int32 kind, Cout, Cin, KH, KW, stride, ky0, kx0, KHs, KWs,
+ *     first_block, pad }
+ * blk2job[b] = job of grid block b (1024 destination elements per block; block b is the (b - first_block)-th of its job).
+ * Replaces the per-layer calls of stil_conv_weight_layout / _phase / stil_transpose on the step path
+ * (models/resnets.py:112-132 nn.Conv2d weights; nn.Linear weights of models/Transformer.py, disentangle_transformer.py). */
+int stil_weight_layouts(const float* src_base, float* dst_base, const void* jobs, const int* blk2job, int n_blocks, void* stream);
+int stil_weight_layout_job_bytes(void);
 int stil_im2col_nchw(const float* x, float* col, int N, int Cin, int H, int W, int OH, int OW, int KH,
                      int KW, int stride, int pad, int Kp, void* stream);
 int stil_transpose(const float* in, float* out, int R, int C, void* stream);

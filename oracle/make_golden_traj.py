@@ -8,9 +8,13 @@ Adam.step, the loop Lightning runs, trainers/evaluate.py:178-179) on five differ
 `mask_random` draws, in the pseudo-label phase (epoch > start_epoch, prototypes pre-filled, crafted heads so that the CGPL
 cases are mixed); the oracle's `full_step` runs the same five steps; the generator asserts oracle == reference on every
 step's loss terms and on the final state, and stores the REFERENCE's per-step losses, its final state (every tensor of the
-small ResNet-18 case) and, per tensor, the oracle-vs-reference distance after five steps (the yardstick for what two
-correct fp32 evaluations of this trajectory can differ by: Adam normalises gradients, so a parameter whose gradient is
-rounding noise moves by +-lr per step in either implementation).
+small ResNet-18 case) and, per tensor, two YARDSTICKS for what correct evaluations of this trajectory differ by (oracle-held): the float64 oracle's distance from
+the reference, and the spread of the fp32 oracle under ONE-ULP perturbations of the initial parameters (NPERT runs).  Adam's
+update is lr * m / sqrt(v) ~ lr * sign(g) in the first steps whatever the gradient's size, so an element whose gradient
+changes sign under rounding lands 2 lr away (1 % of a typical weight): measured here, one ulp in the initial weights moves
+the total loss by ~1e-4 relative within five steps.  A device test can therefore pin the trajectory to a few times that
+spread -- tight enough to catch mistakes in what is carried ACROSS steps (Adam moments and bias correction, the EMA teacher,
+BatchNorm running statistics, prototype sums), which single-step parity cannot see.
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden_traj.py
 """
@@ -38,6 +42,7 @@ HP = dict(model="resnet18", embedding_dim=512, img_size=64, num_classes=5, field
 EPOCH = 3
 TOL_STEP = 2e-5
 B = 8
+NPERT = 4            # one-ulp perturbation runs of the fp32 oracle (sensitivity yardstick)
 SAMPLE = 256        # elements kept per tensor of the final state (strided): the whole ResNet-18 state would be 120 MB
 
 
@@ -124,6 +129,16 @@ def main():
     ora_steps, ora_state = run_oracle(hp, sd, batches, masks)
     o64_steps, o64_state = run_oracle(hp, sd, batches, masks, torch.float64)
     keys = [k for k in ref_steps[0] if k in ora_steps[0]]
+    # sensitivity yardstick: the fp32 oracle from initial parameters perturbed by one ulp (relative 6e-8, seeded)
+    pert_runs = []
+    for trial in range(NPERT):
+        g = torch.Generator().manual_seed(500 + trial)
+        sd_p = {k: (v * (1 + 6e-8 * (torch.rand(v.shape, generator=g) * 2 - 1)) if (v.is_floating_point() and not k.startswith("prototypes")
+                    and not k.endswith("running_var") and not k.endswith("running_mean")) else v.clone()) for k, v in sd.items()}
+        for k in list(sd_p):
+            if k.startswith("model."):
+                sd_p["ema." + k[6:]] = sd_p[k].clone() if sd_p[k].is_floating_point() else sd_p["ema." + k[6:]]
+        pert_runs.append(run_oracle(hp, sd_p, batches, masks))
     worst = 0.0
     for s in range(STEPS):
         for k in keys:
@@ -156,13 +171,16 @@ def main():
         out["sum/" + k] = np.float64(v.double().sum())
         out["norm/" + k] = np.float64(v.double().norm())
         out["dist64/" + k] = np.float64(d64[k])
+        out["distp/" + k] = np.float64(max(float((sample(ps[k]).double() - a).norm() / (a.norm() + 1e-30)) for _, ps in pert_runs))
+        out["dsump/" + k] = np.float64(max(abs(float(ps[k].double().sum()) - float(o.double().sum())) for _, ps in pert_runs))
         out["dsum64/" + k] = np.float64(abs(float(o64_state[k].sum()) - float(v.double().sum())))
     print(f"oracle == reference over {STEPS} steps: worst scaled loss-term distance {worst:.2e}; "
           f"final-state relL2 (sampled) oracle vs reference: median {np.median(list(dist.values())):.2e}, max {max(dist.values()):.2e} "
           f"({max(dist, key=dist.get)}); float64 oracle vs reference: median {np.median(list(d64.values())):.2e}, max {max(d64.values()):.2e}")
     for k in keys:
         out["ref_" + k] = np.array([r[k] for r in ref_steps], dtype=np.float64)          # reference-held
-        out["o64_" + k] = np.array([r[k] for r in o64_steps], dtype=np.float64)          # the float64 oracle's value: the yardstick
+        out["o64_" + k] = np.array([r[k] for r in o64_steps], dtype=np.float64)          # the float64 oracle's value: a yardstick
+        out["sens_" + k] = np.array([max(abs(pr[s_][k] - ora_steps[s_][k]) for pr, _ in pert_runs) for s_ in range(STEPS)], dtype=np.float64)
     path = os.path.join(ROOT, "tests", "golden", "traj_r18.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes; oracle==reference OK")

@@ -800,7 +800,7 @@ def full_step(sd, opt, step_idx, batch, hp, current_epoch, mask_random=None, mi_
     for k in keys:
         sd[k].requires_grad_(False)
     grads = dict(zip(keys, gl))
-    adam_step(sd, grads, opt, step_idx, hp.lr_eval if lr is None else lr, hp.weight_decay_eval)
+    adam_step(sd, grads, opt, step_idx, hp.lr_eval if lr is None else lr, hp.weight_decay_eval, eps=getattr(hp, "adam_eps", 1e-8))
     out = {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in out.items()}
     out["grads"] = grads
     return out

@@ -25,3 +25,4 @@ extern "C" int stil_device_count(void) {
 #include "saint.hip"
 #include "optim.hip"
 #include "augment.hip"
+#include "layout.hip"

@@ -24,6 +24,26 @@ def anneal_lambda(warmup_epochs: int, max_epochs: int):
     return f
 
 
+def host_cpu_share() -> int:
+    """The host cores this job may actually use: min(scheduler affinity, cgroup CPU quota).  The GPU boxes expose every logical
+    CPU of the node (os.cpu_count() = 256) under a cgroup quota of 16 cores per GPU: an OpenMP pool sized by cpu_count runs
+    4.4x SLOWER there than one sized by the quota (measured on a CPU training step: 14.0 s at 128 threads, 3.2 s at 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def init_distributed(backend: Optional[str] = None, timeout_s: Optional[float] = None):
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run). Returns (rank, world, local_rank).
     `timeout_s` (default STIL_DIST_TIMEOUT_S or 900): the process group's timeout -- a rank that never reaches the rendezvous

@@ -10,6 +10,7 @@ one RCCL all-reduce of the gradient slab.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Tuple
 
 import torch
@@ -27,6 +28,8 @@ def _round_up(n, a=ALIGN):
 
 class FlatState:
     def __init__(self, student: nn.Module, teacher: nn.Module, heads: List[nn.Module], device):
+        self._modules_s, self._module_t = [student] + list(heads), teacher
+        self._plans = None            # (student layouts, teacher layouts): layouts.WeightLayouts, built on first refresh
         s_keys, t_keys = set(student.state_dict().keys()), set(teacher.state_dict().keys())
         s_params = [(n, p) for n, p in student.named_parameters()]
         s_bufs = [(n, b) for n, b in student.named_buffers() if b.dtype == torch.float32 and n in s_keys]
@@ -83,9 +86,35 @@ class FlatState:
         for b in self.s_counters + self.t_counters:
             b.data = b.data.to(device)
 
+    # ---- per-step weight re-layouts (layouts.py): one launch for the student (+ heads), one for the teacher
+    def refresh_layouts(self, student: bool = True, teacher: bool = True):
+        """Recompute the GEMM operand layouts of every conv / Linear weight from the CURRENT weights, on the current stream.
+        Called by training_step (student at its start, teacher right after the EMA of its parameters); everything that
+        changes weights invalidates them again (Adam, EMA, load_state_dict), and stale layouts are never used (ops.cached_layout)."""
+        if os.environ.get("STIL_LAYOUT_PLAN", "1") == "0":
+            return
+        if self._plans is None:
+            from .layouts import WeightLayouts
+            self._plans = (WeightLayouts(self.params, self._modules_s, True), WeightLayouts(self.ema, [self._module_t], False))
+            for m in self._modules_s:
+                m.register_load_state_dict_post_hook(lambda *_: self.invalidate_layouts(True, False))
+            self._module_t.register_load_state_dict_post_hook(lambda *_: self.invalidate_layouts(False, True))
+        if student:
+            self._plans[0].refresh()
+        if teacher:
+            self._plans[1].refresh()
+
+    def invalidate_layouts(self, student: bool = True, teacher: bool = True):
+        if self._plans is not None:
+            if student:
+                self._plans[0].invalidate()
+            if teacher:
+                self._plans[1].invalidate()
+
     # ---- EMA teacher
     @torch.no_grad()
     def ema_update(self, momentum: float, eman: bool):
+        self.invalidate_layouts(False, True)
         n = self.n_backbone_state if eman else self.n_backbone_params
         lib().ema_update(_p(self.ema), _p(self.params), n, float(momentum), _stream())
         if eman and self.s_counters:
@@ -94,6 +123,7 @@ class FlatState:
     @torch.no_grad()
     def ema_update_params(self, momentum: float):
         """Parameters only (the BN running buffers follow layer by layer, see modules.TeacherPipe)."""
+        self.invalidate_layouts(False, True)
         lib().ema_update(_p(self.ema), _p(self.params), self.n_backbone_params, float(momentum), _stream())
 
     @torch.no_grad()
@@ -110,6 +140,7 @@ class FlatState:
 
     @torch.no_grad()
     def copy_student_to_teacher(self):
+        self.invalidate_layouts(False, True)
         self.ema.copy_(self.params[: self.n_backbone_state])
         if self.s_counters:
             torch._foreach_copy_(self.t_counters, self.s_counters)
@@ -142,6 +173,7 @@ class FlatState:
     # ---- Adam
     @torch.no_grad()
     def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+        self.invalidate_layouts(True, False)
         act = tuple(1 if t._stil_touched else 0 for t in self.tensors)
         if act != self._active_host:  # changes only when the set of live loss terms changes (epoch boundary)
             self.active.copy_(torch.tensor(act, dtype=torch.uint8))

@@ -136,6 +136,18 @@ def _touch(param):
         _exchange.note(param)
 
 
+def cached_layout(param, attr: str, key=None):
+    """The per-step layout view of a weight (layouts.WeightLayouts: one launch per step for the whole model), or None when
+    the parameter has no plan or the plan is stale -- the caller then runs its own per-call layout kernel."""
+    plan = getattr(param, "_stil_layouts", None)
+    if plan is None or not plan.fresh:
+        return None
+    v = getattr(param, attr, None)
+    if v is None or key is None:
+        return v
+    return v.get(key)
+
+
 def _grad_into(param: torch.Tensor, writer):
     """Run writer(dst, accumulate) for a parameter gradient.  Slab-backed parameters get "+=" into their slot
     (returns None for autograd); plain tensors get a fresh gradient tensor (returned)."""
@@ -278,7 +290,9 @@ class LinearFn(torch.autograd.Function):
             g = gp
         dx = None
         if ctx.needs_input_grad[0]:
-            wt = transpose(weight)  # [K, N]
+            wt = cached_layout(weight, "_stil_wd")  # [K, N]
+            if wt is None:
+                wt = transpose(weight)
             dx = gemm_nt(g, wt, M, K, N).reshape(ctx.xshape)
         dw = wgrad_param(weight, g, x2, M, N, K) if ctx.needs_input_grad[1] else None
         db = None
@@ -384,8 +398,10 @@ class ConvBnActFn(torch.autograd.Function):
             if k == 1:
                 wf = w.reshape(Cout, Cin)
             else:
-                wf = torch.empty((Cout, k * k * Cin), dtype=torch.float32, device=dev)
-                lib().conv_weight_layout(_p(w), _p(wf), None, Cout, Cin, k, k, _stream())
+                wf = cached_layout(w, "_stil_wf")
+                if wf is None:
+                    wf = torch.empty((Cout, k * k * Cin), dtype=torch.float32, device=dev)
+                    lib().conv_weight_layout(_p(w), _p(wf), None, Cout, Cin, k, k, _stream())
             geom = _conv_geom_fwd(H, W_, Cin, OH, OW, k, stride, pad)
             y = gemm_nt(x, wf, M, Cout, k * k * Cin, geom=geom, colstats=ts, a_bn=xstats)
         stats = torch.empty((4, Cout), dtype=torch.float32, device=dev)
@@ -463,11 +479,15 @@ class ConvBnActFn(torch.autograd.Function):
                 if cell is not None:
                     cell["masked"] = True   # both stride-1 branches below apply the mask
                 if k == 1 and stride == 1:
-                    wd = transpose(w.reshape(Cout, Cin))  # [Cin, Cout]
+                    wd = cached_layout(w, "_stil_wd")  # [Cin, Cout]
+                    if wd is None:
+                        wd = transpose(w.reshape(Cout, Cin))
                     dx = gemm_nt(dy, wd, M, Cin, Cout, resid=ga, relu_mask=zmask).view(Nb, H, W_, Cin)
                 elif stride == 1:
-                    wd = torch.empty((Cin, k * k * Cout), dtype=torch.float32, device=dev)
-                    lib().conv_weight_layout(_p(w), None, _p(wd), Cout, Cin, k, k, _stream())
+                    wd = cached_layout(w, "_stil_wd")
+                    if wd is None:
+                        wd = torch.empty((Cin, k * k * Cout), dtype=torch.float32, device=dev)
+                        lib().conv_weight_layout(_p(w), None, _p(wd), Cout, Cin, k, k, _stream())
                     g2 = (OH, OW, Cout, H, W_, k, k, stride, pad, 1)
                     dx = gemm_nt(dy, wd, Nb * H * W_, Cin, k * k * Cout, geom=g2, resid=ga, relu_mask=zmask).view(Nb, H, W_, Cin)
                 else:
@@ -504,8 +524,10 @@ def strided_dgrad(dy, w, Nb, H, W_, Cin, OH, OW, Cout, k, stride, pad):
             if KWs == 0 or Ws == 0:
                 continue
             dx0 = (px + pad - kx0) // stride
-            wsub = torch.empty((Cin, KHs * KWs * Cout), dtype=torch.float32, device=dev)
-            lib().conv_weight_layout_phase(_p(w), _p(wsub), Cout, Cin, k, k, stride, ky0, kx0, KHs, KWs, _stream())
+            wsub = cached_layout(w, "_stil_wphase", (py, px))
+            if wsub is None:
+                wsub = torch.empty((Cin, KHs * KWs * Cout), dtype=torch.float32, device=dev)
+                lib().conv_weight_layout_phase(_p(w), _p(wsub), Cout, Cin, k, k, stride, ky0, kx0, KHs, KWs, _stream())
             # iy = oy' + dy0 - jy = oy' - pad' + ky'  with ky' = KHs-1-jy, pad' = KHs-1-dy0
             geom = (OH, OW, Cout, Hs, Ws, KHs, KWs, 1, 0, 0)
             gemm_nt(dy, wsub, Nb * Hs * Ws, Cin, KHs * KWs * Cout, geom=geom, out=dx, pads=(KHs - 1 - dy0, KWs - 1 - dx0),
@@ -531,8 +553,10 @@ def conv_bn_eval(x, w, gamma, beta, rmean, rvar, resid, k, stride, pad, relu, st
     if k == 1:
         wf = w.reshape(Cout, Cin)
     else:
-        wf = torch.empty((Cout, k * k * Cin), dtype=torch.float32, device=dev)
-        lib().conv_weight_layout(_p(w), _p(wf), None, Cout, Cin, k, k, _stream())
+        wf = cached_layout(w, "_stil_wf")
+        if wf is None:
+            wf = torch.empty((Cout, k * k * Cin), dtype=torch.float32, device=dev)
+            lib().conv_weight_layout(_p(w), _p(wf), None, Cout, Cin, k, k, _stream())
     z = gemm_nt(x, wf, M, Cout, k * k * Cin, geom=_conv_geom_fwd(H, W_, Cin, OH, OW, k, stride, pad), sub=ab[2], scale=ab[0],
                 shift=ab[1], resid=resid, act=1 if relu else 0)
     return z.view(Nb, OH, OW, Cout)

@@ -369,9 +369,11 @@ class STiLModel(_Base):
         # operands, same results as "student, then momentum_update_ema, then teacher" (STiLModel.py:248-257).
         side = ops.side_stream(dev) if self.use_ema else None
         pipe = None
+        self.flat.refresh_layouts(student=True, teacher=False)   # every GEMM operand layout of the student in one launch
         if side is not None:
             with torch.no_grad():
                 self.flat.ema_update_params(hp.ema_momentum)
+            self.flat.refresh_layouts(student=False, teacher=True)   # ... and of the teacher, from its averaged parameters
             pipe = TeacherPipe(self.flat, hp.ema_momentum, bool(hp.eman))
             pipe.start.record()
             set_teacher_pipe(pipe)
@@ -400,6 +402,7 @@ class STiLModel(_Base):
                 ym_e, yi_e, yt_e = t[0], t[1], t[2]
             elif self.use_ema:
                 self.flat.ema_update(hp.ema_momentum, bool(hp.eman))
+                self.flat.refresh_layouts(student=False, teacher=True)
                 t = self.ema.forward_all((x_img, x_tab), train=False, cache=cache)
                 feat_m_e, _, _ = self.project_3features(torch.cat((t[3], t[9], t[6]), dim=1))
                 ym_e, yi_e, yt_e = t[0], t[1], t[2]

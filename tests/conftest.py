@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the oracle passes run on the host cores: size torch's pool by the job's CPU share, not by the node's CPU count (driver.host_cpu_share)
+    try:
+        import torch
+        from stil_tta_amd.driver import host_cpu_share
+        torch.set_num_threads(min(torch.get_num_threads(), host_cpu_share()))
+    except Exception:
+        pass
 
 
 def _has_gpu():

@@ -715,3 +715,78 @@ def test_onehot_argmax_first_maximum_and_threshold(ops):
     lib().onehot_argmax(p.data_ptr(), 3, 4, 0.5, oh.data_ptr(), mask.data_ptr(), idx.data_ptr(), None)
     assert idx.tolist() == [1, 0, 0] and mask.tolist() == [1.0, 1.0, 0.0]
     assert torch.equal(oh.cpu(), torch.nn.functional.one_hot(torch.tensor([1, 0, 0]), 4).float())
+
+
+def test_weight_layout_plan_equals_the_per_call_layouts_bit_for_bit(ops):
+    """layouts.WeightLayouts (ONE launch for every conv / Linear weight of a model, csrc/layout.hip) against the per-call
+    kernels it replaces on the step path (stil_conv_weight_layout / _phase / stil_transpose): identical bytes for every view,
+    stale plans are never used, and a whole ResNet-18 STiL step runs bit-identically with and without the plan."""
+    import torch.nn as nn
+    from stil_tta_amd._lib import lib
+    from stil_tta_amd.layouts import WeightLayouts, phase_specs
+    from stil_tta_amd.ops import _p, _stream, cached_layout
+    torch.manual_seed(3)
+    net = nn.Sequential(nn.Conv2d(16, 32, 3, padding=1, bias=False), nn.Conv2d(32, 64, 3, stride=2, padding=1, bias=False), nn.Conv2d(64, 24, 1, bias=False),
+                        nn.Conv2d(24, 40, 1, stride=2, bias=False), nn.Conv2d(3, 8, 7, stride=2, padding=3, bias=False), nn.Linear(70, 33), nn.Linear(64, 128, bias=False))
+    total = sum((p.numel() + 1023) // 1024 * 1024 for p in net.parameters())
+    slab = torch.zeros(total, device="cuda")
+    o = 0
+    for p in net.parameters():
+        v = slab[o:o + p.numel()].view(p.shape)
+        v.copy_(p.data)
+        p.data = v
+        o += (p.numel() + 1023) // 1024 * 1024
+    plan = WeightLayouts(slab, [net], True)
+    assert plan.n_jobs == 2 + (1 + 4) + 1 + 1 + 2 and not hasattr(net[4].weight, "_stil_wf")   # the 3-channel stem is not planned
+    assert cached_layout(net[0].weight, "_stil_wf") is None                                      # not refreshed yet: stale
+    plan.refresh()
+    L = lib()
+    for m in net:
+        w = m.weight
+        if isinstance(m, nn.Linear):
+            assert torch.equal(cached_layout(w, "_stil_wd"), ops.transpose(w.detach()))
+            continue
+        Cout, Cin, k, _ = w.shape
+        if Cin % 4:
+            continue
+        s_, pad = m.stride[0], m.padding[0]
+        wf, wd = torch.empty(Cout, k * k * Cin, device="cuda"), torch.empty(Cin, k * k * Cout, device="cuda")
+        L.conv_weight_layout(_p(w), _p(wf), _p(wd), Cout, Cin, k, k, _stream())
+        if k > 1:
+            assert torch.equal(cached_layout(w, "_stil_wf"), wf)
+        if s_ == 1:
+            assert torch.equal(cached_layout(w, "_stil_wd"), wd)
+        else:
+            specs = phase_specs(k, s_, pad)
+            assert len(specs) == (4 if k == 3 else 1)
+            for (py, px, ky0, kx0, KHs, KWs) in specs:
+                ws = torch.empty(Cin, KHs * KWs * Cout, device="cuda")
+                L.conv_weight_layout_phase(_p(w), _p(ws), Cout, Cin, k, k, s_, ky0, kx0, KHs, KWs, _stream())
+                assert torch.equal(cached_layout(w, "_stil_wphase", (py, px)), ws), (k, py, px)
+    plan.invalidate()
+    assert cached_layout(net[0].weight, "_stil_wd") is None
+    # the whole step with and without the plan
+    import os
+    from stil_tta_amd import STiLModel
+    from stil_tta_amd.driver import synthetic_batch, train_step
+    from stil_tta_amd.flat import StilAdam
+    fl = [3, 4] + [1] * 3
+    outs = []
+    for flag in ("1", "0"):
+        os.environ["STIL_LAYOUT_PLAN"] = flag
+        try:
+            torch.manual_seed(0)
+            m = STiLModel(dict(model="resnet18", embedding_dim=512, field_lengths=fl, num_classes=5, start_epoch=0, batch_size=16, th1=0.3, mi_dropout=False))
+            m.setup_device("cuda"); m.train(); m.current_epoch = 1
+            m.prototypes.copy_(F.normalize(torch.randn(5, 128, generator=torch.Generator().manual_seed(1))).cuda())
+            opt = StilAdam(m.flat, lr=1e-3)
+            b = synthetic_batch(fl, 5, 16, 64, seed=3, device="cuda")
+            mr = (torch.arange(14) % 2 == 0).cuda()
+            for _ in range(2):
+                loss = train_step(m, opt, b, mask_random=mr)
+            torch.cuda.synchronize()
+            assert (m.flat._plans is not None) == (flag == "1")
+            outs.append((float(loss), m.flat.params.clone(), m.flat.grads.clone(), m.flat.ema.clone()))
+        finally:
+            os.environ.pop("STIL_LAYOUT_PLAN")
+    assert outs[0][0] == outs[1][0] and all(torch.equal(a, b_) for a, b_ in zip(outs[0][1:], outs[1][1:]))

@@ -454,10 +454,12 @@ def test_five_step_trajectory_matches_oracle():
     ResNet-18 case in the pseudo-label phase against the trajectory the REAL reference took on the same five seeded batches
     and mask_random draws (tests/golden/traj_r18.npz, written by oracle/make_golden_traj.py): every loss term of every step,
     the logged mask / case ratios exactly, and the final state (strided sample + sum of every tensor).  Single-step parity
-    cannot see a slow drift; this can.  Yardstick: Adam normalises gradients, so two correct fp32 evaluations separate along
-    the trajectory (a weight whose gradient is rounding noise moves +-lr per step in either); the fixture therefore carries,
-    for every quantity, the float64 oracle's distance from the reference -- the device must stay as close to the reference
-    as float64 does: |gpu - ref| <= 3 |f64 - ref| + TOL (1 + |ref|)."""
+    cannot see what is carried ACROSS steps (Adam moments and bias correction, EMA teacher, BatchNorm running statistics,
+    prototype sums); this can.  Yardstick: Adam's update is ~lr * sign(g) whatever the gradient's size, so two correct fp32
+    evaluations separate along the trajectory (an element whose gradient changes sign under rounding lands 2 lr away); the
+    fixture carries, for every quantity, how far the float64 oracle is from the reference and how far the fp32 oracle moves
+    under one-ulp perturbations of the initial weights (~1e-4 of the loss within five steps).  The device must stay within
+    three times that spread: |gpu - ref| <= 3 max(|f64 - ref|, spread) + TOL (1 + |ref|)."""
     from stil_tta_amd.driver import train_step
     from stil_tta_amd.flat import StilAdam
     from oracle import make_golden_traj as T
@@ -475,7 +477,7 @@ def test_five_step_trajectory_matches_oracle():
         torch.cuda.synchronize()
         for k, lk in names.items():
             got, ref, f64 = float(m.last[lk].detach()), float(fx["ref_" + k][s_]), float(fx["o64_" + k][s_])
-            bound = 3 * abs(f64 - ref) + TOL * (1 + abs(ref))
+            bound = 3 * max(abs(f64 - ref), float(fx["sens_" + k][s_])) + TOL * (1 + abs(ref))
             worst = max(worst, abs(got - ref) / bound)
             if abs(got - ref) > bound:
                 bad.append((s_, k, got, ref, f64))
@@ -497,15 +499,15 @@ def test_five_step_trajectory_matches_oracle():
         got = f[::max(1, f.numel() // n_s)][:n_s].double().numpy()
         ref = fx[key].astype(np.float64)
         err = float(np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30))
-        bound = 3 * float(fx["dist64/" + k]) + 1e-4
+        bound = 3 * max(float(fx["dist64/" + k]), float(fx["distp/" + k])) + 1e-4
         ratios.append(err / bound)
         if err > bound:
-            bad.append(("state " + k, err, float(fx["dist64/" + k])))
+            bad.append(("state " + k, err, float(fx["dist64/" + k]), float(fx["distp/" + k])))
         dsum = abs(float(v.double().sum()) - float(fx["sum/" + k]))
-        sbound = 3 * float(fx["dsum64/" + k]) + 1e-4 * (1.0 + abs(float(fx["sum/" + k])) + float(fx["norm/" + k]))
+        sbound = 3 * max(float(fx["dsum64/" + k]), float(fx["dsump/" + k])) + 1e-4 * (1.0 + abs(float(fx["sum/" + k])) + float(fx["norm/" + k]))
         sums.append(dsum / sbound)
         if dsum > sbound:
-            bad.append(("sum " + k, dsum, float(fx["dsum64/" + k])))
+            bad.append(("sum " + k, dsum, float(fx["dsum64/" + k]), float(fx["dsump/" + k])))
     print(f"trajectory: worst loss-term error / bound {worst:.3f}; final state (sampled relL2) error / bound: median {np.median(ratios):.3f}, "
           f"p90 {np.percentile(ratios, 90):.3f}, max {np.max(ratios):.3f}; checksum error / bound: max {np.max(sums):.3f}")
     assert not bad, f"{len(bad)} mismatches, first: {bad[:12]}"

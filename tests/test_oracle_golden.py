@@ -68,7 +68,7 @@ def test_oracle_trajectory_matches_reference_golden():
             got, ref = T.sample(state[key[6:]]).double().numpy(), fx[key].astype(np.float64)
             err = np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30)
             # a weight whose gradient is rounding noise moves +-lr per Adam step: thread-count-dependent reductions may flip it
-            assert err <= 3 * float(fx["dist64/" + key[6:]]) + 1e-4, (key, err)
+            assert err <= 3 * max(float(fx["dist64/" + key[6:]]), float(fx["distp/" + key[6:]])) + 1e-4, (key, err)
 
 
 def test_epoch_end_commits_prototypes():
