@@ -47,7 +47,17 @@ int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, 
                  int mode, int out_stride, int out_py, int out_px, int out_OH, int out_OW,
                  const float* bias, const float* sub, const float* scale, const float* shift, const float* resid,
                  int ldr, float* pre, int act, float alpha, float* colstats, const float* a_bn, const float* relu_mask, int ldm,
+                 const float* bs_y, const float* bs_stats, float* bstats, int bs_relu, int bs_tile0,
                  int tune, void* stream);
+/* `bstats` (optional; 64x64 tiles with the 16-byte epilogue: stil_gemm_nt_bstats_ok): this launch produces the gradient g w.r.t.
+ *   the output z = [relu](BN(y)) of a training conv+BN layer (it is the input-gradient GEMM of that layer's consumer).  The
+ *   epilogue then also leaves the BatchNorm-BACKWARD partial sums of that layer, per 64-row tile t = bs_tile0 + tile index:
+ *   bstats[(2t)*N + c] = sum_rows g'[., c], bstats[(2t+1)*N + c] = sum_rows g'[., c] * xhat[., c], xhat = (y - mean) * rstd,
+ *   g' = g (bs_relu 0: g already carries the ReLU mask through relu_mask, or the layer has no ReLU) or g * [(y - mean)*a + beta > 0]
+ *   (bs_relu 2).  bs_y: that layer's raw conv output, shaped and indexed like C (row stride ldc); bs_stats: its statistics block
+ *   [4][N].  stil_bn_train_bwd_tiles consumes them: the reduction pass of BatchNorm backward over g and y (models/resnets.py:
+ *   112-132, nn.BatchNorm2d backward) disappears.  bs_tile0 lets the phase launches of a strided input-gradient fill one array. */
+int stil_gemm_nt_bstats_ok(const float* C, int N, int ldc, const float* resid, int ldr, const float* relu_mask, int ldm, const float* bs_y);
 /* `relu_mask` (optional, row stride ldm, shaped like C): the stored value is zeroed where relu_mask <= 0.  The input-gradient
  *   GEMM of a block's first conv writes the gradient of the PREVIOUS block's output already multiplied by that output's ReLU
  *   mask (models/resnets.py:129-130: out += identity; out = relu(out)), so that block's BatchNorm backward neither reads z
@@ -55,10 +65,12 @@ int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, 
 /* `a_bn` (optional; forward gathers with srcC % 16 == 0, 16-byte aligned operands): the A source is the RAW output y of a
  *   training conv+BN+ReLU layer and a_bn that layer's statistics block [4][srcC] (mean, rstd, a = gamma * rstd, beta, as
  *   stil_bn_train_fwd_tiles writes it); z = relu((y - mean) * a + beta) is formed while A is staged, so the inner layers of a
- *   residual block never materialise z (models/resnets.py:112-132: bn1/relu, bn2/relu fused into conv2 / conv3).
+ *   residual block never materialise z (models/resnets.py:112-132: bn1/relu, bn2/relu fused into conv2 / conv3).  Always
+ *   64x64 tiles with 16-deep k-tiles: `tune` must leave the tile automatic or ask for 11 (colstats is sized by tile rows).
  * `tune` (0 = automatic; otherwise for A/B measurements) = variant + 100 * bk32 + 1000 * acc2:
  *   variant  block tile: 22 = 128x128, 21 = 128x64, 12 = 64x128, 11 = 64x64 (0: automatic = 64x64, the fastest on the shapes of the step);
- *   bk32     32-deep LDS k-tiles instead of 16: 0 = automatic (plain products with K >= 256), 1 = wherever possible, 2 = never;
+ *   bk32     32-deep LDS k-tiles instead of 16: 0 = automatic (plain products: two LDS buffers for K >= 256, one below),
+ *            1 = wherever possible (two LDS buffers), 2 = never, 3 = wherever possible in ONE LDS buffer (64x64 tiles);
  *   acc2     two-level accumulation (partial chains of 64 products added to a master accumulator, ~ATen-CPU's
  *            rounding noise for long reductions): 0 = for K >= 512, 1 = never, 2 = always.
  *   + 10000  scalar epilogue (one dword per lane) instead of the 16-byte one 64x64 tiles use when N, ldc, ldr % 4 == 0 and
@@ -66,8 +78,9 @@ int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, 
  * rows per output tile / tile variant stil_gemm_nt uses for an [M,N] output under `tune` (colstats granularity, bench bookkeeping) */
 int stil_gemm_nt_tile_rows(int M, int N, int tune);
 int stil_gemm_nt_variant(int M, int N, int tune);
-/* the instantiation stil_gemm_nt launches for these operands: variant + 100 * bk32 + 1000 * acc2 + 10000 * vec (16-byte
- * loads) + 100000 * plain (`plain` = 1: 1x1 / stride 1 / no padding / identity output map -- A is a plain row-major matrix
+/* the instantiation stil_gemm_nt launches for these operands, as a CONFIG code whose digits are NOT the tune digits:
+ * variant + 100 * bkd (0 = 16-deep k-tiles, 1 = 32-deep in two LDS buffers, 2 = 32-deep in one) + 1000 * acc2 (1 = two-level
+ * sums, 0 = single chain) + 10000 * vec (16-byte loads; unrelated to tune's "+ 10000 scalar epilogue") + 100000 * plain (`plain` = 1: 1x1 / stride 1 / no padding / identity output map -- A is a plain row-major matrix
  * and the kernel's geometry code is compiled out) + 1000000 * a_bn (the operand-staging BatchNorm instantiation) */
 int stil_gemm_nt_config(const float* A, const float* W, int M, int N, int K, int lda, int ldb, int srcC, int KH, int KW, int plain, int a_bn, int tune);
 
@@ -131,6 +144,13 @@ int stil_bn_train_bwd(const float* dz, const float* z, const float* x, const flo
                       const float* stats, float* dx, float* gout, float* dgamma, float* dbeta, float* coef,
                       int M, int C, int relu, int accumulate, float* workspace, size_t workspace_bytes,
                       void* stream);
+/* BatchNorm backward whose reduction pass was done by the GEMM that produced dz (stil_gemm_nt `bstats`): tilestats
+ * [2*ntiles][C] (row 2t = sum g', row 2t+1 = sum g' * xhat over tile t) are combined in double in a fixed order, then the dx
+ * pass of stil_bn_train_bwd runs (relu: the mask the sums were formed with).  nn.BatchNorm2d backward, models/resnets.py:112-132. */
+size_t stil_bn_bwd_tiles_workspace_bytes(int ntiles, int C);
+int stil_bn_train_bwd_tiles(const float* dz, const float* z, const float* x, const float* gamma, const float* stats,
+                            const float* tilestats, int ntiles, float* dx, float* dgamma, float* dbeta, float* coef,
+                            int M, int C, int relu, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 int stil_maxpool3x3s2_fwd(const float* x, float* y, unsigned char* idx, int N, int H, int W, int C, int OH,
                           int OW, void* stream);
 int stil_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, float* dx, int N, int H, int W, int C,

@@ -143,6 +143,10 @@ class GradExchange:
         wk.synchronize() if isinstance(wk, torch.cuda.Event) else wk.wait()
         v = t.tolist()
         if v[0] != -v[1] or v[2] != -v[3]:
+            # A rank in overlap mode may already have bucket all-reduces in flight that its peers will never match: tear the
+            # communicator down before raising, so that no rank is left spinning in a collective (on the GPU: RCCL kernels
+            # that would block process teardown in the process group's destructor).
+            _abort_process_group()
             raise RuntimeError(f"data-parallel ranks disagree on the gradient exchange of this step (this rank: {what}; "
                                f"hash max/min {v[0]}/{-v[1]}, mode max/min {v[2]}/{-v[3]}): refusing to issue mismatched collectives")
 
@@ -230,8 +234,11 @@ class GradExchange:
             # post-backward exchange: EVERY bucket, in index order -- the same sequence on every rank whatever its
             # autograd engine did.  On a LEARNING step first make sure all ranks are here in this mode (a rare step: the
             # host read is free); steady post-backward steps are verified one step later, like overlap steps.
-            learning = self.sig is not None and self.enabled and self.sig not in self.plans
-            if learning and not self._capturing():
+            # Inside a hipGraph capture nothing may synchronise with the host: the agreement below (a broadcast, an all-reduce
+            # and two host reads) cannot run, so a captured first step does NOT learn -- it keeps the post-backward exchange
+            # and leaves the signature out of `plans`; the next eager step under this signature learns it.
+            learning = self.sig is not None and self.enabled and self.sig not in self.plans and not self._capturing()
+            if learning:
                 self.verify()
             pending = list(range(len(self.ranges)))
             if learning:
@@ -253,6 +260,27 @@ class GradExchange:
         if self.bad:
             raise RuntimeError(self.bad)
         return 1.0 / world_size()
+
+
+def _abort_process_group():
+    """Best effort: abort (not destroy: destroy waits for pending work) the default process group's backend."""
+    try:
+        pg = dist.distributed_c10d._get_default_group()
+        for dev in ("cuda", "cpu"):
+            try:
+                be = pg._get_backend(torch.device(dev))
+            except Exception:
+                continue
+            for name in ("abort", "_abort", "_shutdown"):
+                fn = getattr(be, name, None)
+                if fn is not None:
+                    try:
+                        fn()
+                    except Exception:
+                        pass
+                    break
+    except Exception:
+        pass
 
 
 def allreduce_flat(slab: torch.Tensor, bucket_elems: int = 64 << 20) -> float:

@@ -293,6 +293,48 @@ __global__ __launch_bounds__(256) void bn_bwd_final4_kernel(const float* __restr
   }
 }
 
+// ---- backward statistics from per-tile partials: the input-gradient GEMM that PRODUCED dz left, per 64-row tile t and column,
+// ts[(2t)*C + c] = sum g', ts[(2t+1)*C + c] = sum g' * xhat (stil_gemm_nt `bstats`), so no pass over dz and x is needed.  Two short
+// kernels combine them in DOUBLE in a fixed order (stage 1: nsplit blocks per 32 columns, 8 tile lanes each; final: the
+// nsplit sums), then write what bn_bwd_final_kernel writes.
+__global__ __launch_bounds__(256) void bn_bwd_tiles_stage1_kernel(const float* __restrict__ ts, int nt, int C, int tiles_per_split,
+                                                                   double* __restrict__ part) {
+  __shared__ double sh[2 * 8 * 32];
+  const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const int t0 = blockIdx.y * tiles_per_split, t1 = min(nt, t0 + tiles_per_split);
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int t = t0 + lane; t < t1; t += 8) {
+      s1 += (double)ts[((long)t * 2) * C + c];
+      s2 += (double)ts[((long)t * 2 + 1) * C + c];
+    }
+  sh[lane * 32 + cl] = s1; sh[256 + lane * 32 + cl] = s2;
+  __syncthreads();
+  if (lane != 0 || c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int l = 0; l < 8; ++l) { a += sh[l * 32 + cl]; b += sh[256 + l * 32 + cl]; }
+  const int nsplit = gridDim.y;
+  part[((long)0 * nsplit + blockIdx.y) * C + c] = a;
+  part[((long)1 * nsplit + blockIdx.y) * C + c] = b;
+}
+__global__ __launch_bounds__(256) void bn_bwd_tiles_final_kernel(const double* __restrict__ part, int nsplit, int M, int C,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                  float* __restrict__ coef, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int k = 0; k < nsplit; ++k) { a += part[((long)0 * nsplit + k) * C + c]; b += part[((long)1 * nsplit + k) * C + c]; }
+  const float s1 = (float)a, s2 = (float)b;
+  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + s1 : s1;
+  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + s2 : s2;
+  const float invM = 1.f / (float)M;
+  coef[c] = gamma[c] * stats[C + c];
+  coef[C + c] = s1 * invM;
+  coef[2 * C + c] = s2 * invM;
+}
+
 // dx = gamma*rstd * (g - dbeta/M - xhat*dgamma/M)
 __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict__ dz, const float* __restrict__ z,
                                                          const float* __restrict__ x, const float* __restrict__ stats,
@@ -551,6 +593,37 @@ extern "C" int stil_bn_train_bwd(const float* dz, const float* z, const float* x
   // if g was materialised, read it (already masked) instead of dz,z
   hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(grid), dim3(256), 0, s, gout ? gout : dz, z, x, stats, coef, dx, total4, C,
                      gout ? 0 : relu);
+  STIL_LAUNCH_CHECK();
+  return STIL_OK;
+}
+
+// BatchNorm backward when the GEMM that produced dz already left the per-tile sums (stil_gemm_nt `bstats`): statistics from
+// `tilestats` [2*ntiles][C] (two short kernels), then the dx pass of stil_bn_train_bwd.  relu as there (the mask the sums were
+// formed with: 0 = dz is final, 2 = recomputed from x and the statistics; 1 = from z).
+static inline int bn_bwd_tiles_nsplit(int nt) { return cdiv(nt, 256); }
+extern "C" size_t stil_bn_bwd_tiles_workspace_bytes(int ntiles, int C) {
+  if (ntiles <= 0 || C <= 0) return 0;
+  return (size_t)2 * bn_bwd_tiles_nsplit(ntiles) * C * sizeof(double);
+}
+extern "C" int stil_bn_train_bwd_tiles(const float* dz, const float* z, const float* x, const float* gamma, const float* stats,
+                                       const float* tilestats, int ntiles, float* dx, float* dgamma, float* dbeta, float* coef,
+                                       int M, int C, int relu, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  STIL_REQUIRE(dz && x && gamma && stats && tilestats && dx && coef && workspace, "stil_bn_train_bwd_tiles: null pointer");
+  STIL_REQUIRE(relu >= 0 && relu <= 2 && (relu != 1 || z), "stil_bn_train_bwd_tiles: relu must be 0, 1 (needs z) or 2");
+  STIL_REQUIRE(ntiles > 0 && M > 0 && C % 4 == 0, "stil_bn_train_bwd_tiles: bad shape M=%d C=%d ntiles=%d", M, C, ntiles);
+  STIL_REQUIRE(workspace_bytes >= stil_bn_bwd_tiles_workspace_bytes(ntiles, C) && ((uintptr_t)workspace % 8) == 0,
+               "stil_bn_train_bwd_tiles: workspace too small or not 8-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int nsplit = bn_bwd_tiles_nsplit(ntiles);
+  hipLaunchKernelGGL(bn_bwd_tiles_stage1_kernel, dim3(cdiv(C, 32), nsplit), dim3(256), 0, s, tilestats, ntiles, C, cdiv(ntiles, nsplit),
+                     (double*)workspace);
+  STIL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_tiles_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)workspace, nsplit, M, C, gamma, stats,
+                     dgamma, dbeta, coef, accumulate);
+  STIL_LAUNCH_CHECK();
+  long total4 = (long)M * C / 4;
+  int grid = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
+  hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(grid), dim3(256), 0, s, dz, z, x, stats, coef, dx, total4, C, relu);
   STIL_LAUNCH_CHECK();
   return STIL_OK;
 }

@@ -55,6 +55,17 @@ struct GemmNTArgs {
   const float* rmask;  // optional [rows, ldc]-shaped tensor (row stride ldm): the stored value is zeroed where rmask <= 0 -- the ReLU
   int ldm;             // mask of the block output whose gradient this launch produces (pre-masked residual gradient)
   int wide;   // 1: 16-byte epilogue (64x64 tiles; N, ldc, ldr % 4 == 0 and C / resid / pre / per-column vectors 16-byte aligned)
+  // optional BatchNorm-BACKWARD statistics of the layer whose output gradient this launch produces (wide epilogue only): the
+  // stored value g (after residual / mask) is the gradient w.r.t. z = [relu](BN(y)); per tile and column the epilogue leaves
+  //   bstats[(t*2 + 0)*N + col] = sum_rows g',   bstats[(t*2 + 1)*N + col] = sum_rows g' * xhat,   xhat = (y - mean) * rstd
+  // with g' = g (bs_relu 0: g already carries the ReLU mask, or the layer has no ReLU) or g * [(y - mean)*a + beta > 0]
+  // (bs_relu 2: the mask recomputed from y exactly as the forward formed z) -- what bn_bwd_partial_kernel computes in a pass of
+  // its own over g and y (models/resnets.py:112-132 backward).  bs_y: that layer's raw conv output, indexed like the output
+  // (row stride ldbs); bs_stats: its statistics block [4][N] (mean, rstd, a, beta); t = bs_tile0 + this launch's row-tile index.
+  const float* bs_y;
+  const float* bs_stats;
+  float* bstats;
+  int ldbs, bs_relu, bs_tile0;
 };
 
 __device__ __forceinline__ float4 ld4_guard(const float* p, int nvalid, int vec) {
@@ -192,6 +203,54 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNTArgs& p, f32x16 (&a
             v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
           }
           *reinterpret_cast<float4*>(p.C + row * p.ldc + col) = v;
+          if (p.bstats) *reinterpret_cast<float4*>(T + rl * TS + cq) = v;   // the stored gradient, for the statistics loop below (own slot)
+        }
+      }
+      if (p.bstats) {   // block-uniform.  A loop of its own (the affine / bias registers are dead by now: no spills in the hot kernels)
+        float4 bs1 = make_float4(0.f, 0.f, 0.f, 0.f), bs2 = bs1;   // this thread's 4 rows x 4 columns of (g', g' * xhat)
+        if (col < p.N) {
+          const float4 bmu = *reinterpret_cast<const float4*>(p.bs_stats + col);
+          const float4 brs = *reinterpret_cast<const float4*>(p.bs_stats + p.N + col);
+          const float4 bap = *reinterpret_cast<const float4*>(p.bs_stats + 2 * p.N + col);
+          const float4 bbp = *reinterpret_cast<const float4*>(p.bs_stats + 3 * p.N + col);
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps) {
+            const int rl = ps * 16 + (tid >> 4), row_m = tm * BM + rl;
+            if (row_m >= p.M) continue;
+            long row = row_m;
+            if (!PLAIN && p.os != 1) {
+              const int ohw = g.OH * g.OW;
+              const int n = row_m / ohw, rem = row_m - n * ohw;
+              const int oy = rem / g.OW, ox = rem - oy * g.OW;
+              row = ((long)n * p.oOH + oy * p.os + p.opy) * p.oOW + ox * p.os + p.opx;
+            }
+            const float4 yy = *reinterpret_cast<const float4*>(p.bs_y + row * p.ldbs + col);
+            float4 gg = *reinterpret_cast<const float4*>(T + rl * TS + cq);
+            if (p.bs_relu == 2) {   // the sign of z = (y - mean)*a + beta, as bn_bwd_partial_kernel / the operand staging form it
+              gg.x = ((yy.x - bmu.x) * bap.x + bbp.x) > 0.f ? gg.x : 0.f; gg.y = ((yy.y - bmu.y) * bap.y + bbp.y) > 0.f ? gg.y : 0.f;
+              gg.z = ((yy.z - bmu.z) * bap.z + bbp.z) > 0.f ? gg.z : 0.f; gg.w = ((yy.w - bmu.w) * bap.w + bbp.w) > 0.f ? gg.w : 0.f;
+            }
+            bs1.x += gg.x; bs2.x += gg.x * ((yy.x - bmu.x) * brs.x);
+            bs1.y += gg.y; bs2.y += gg.y * ((yy.y - bmu.y) * brs.y);
+            bs1.z += gg.z; bs2.z += gg.z * ((yy.z - bmu.z) * brs.z);
+            bs1.w += gg.w; bs2.w += gg.w * ((yy.w - bmu.w) * brs.w);
+          }
+        }
+        // 16 row-threads per column quad -> LDS -> one fixed-order sum per column (deterministic)
+        __syncthreads();                    // everybody is done reading T
+        float* R1 = red;                    // [16][64] sums of g', then [16][64] sums of g' * xhat  (8 KB <= T's 17 KB)
+        float* R2 = red + 16 * 64;
+        const int rt = tid >> 4;
+        *reinterpret_cast<float4*>(R1 + rt * 64 + cq) = bs1;
+        *reinterpret_cast<float4*>(R2 + rt * 64 + cq) = bs2;
+        __syncthreads();
+        if (tid < 128) {
+          const int c = tid & 63, which = tid >> 6, gc = tn * BN + c;
+          const float* R = which ? R2 : R1;
+          float t = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t += R[r * 64 + c];
+          if (gc < p.N) p.bstats[((long)(p.bs_tile0 + tm) * 2 + which) * p.N + gc] = t;
         }
       }
       return;
@@ -776,6 +835,13 @@ extern "C" int stil_gemm_nt_variant(int M, int N, int tune) {
   return 11;
 }
 
+// may a launch with these output-side operands carry `bstats`?  (the 16-byte epilogue's conditions, as stil_gemm_nt derives them)
+extern "C" int stil_gemm_nt_bstats_ok(const float* C, int N, int ldc, const float* resid, int ldr, const float* relu_mask, int ldm, const float* bs_y) {
+  auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q % 16) == 0; };
+  return (N % 4 == 0) && (ldc % 4 == 0) && (!resid || ldr % 4 == 0) && (!relu_mask || ldm % 4 == 0) && al16(relu_mask) && al16(C) && al16(resid) &&
+         al16(bs_y) && bs_y != nullptr ? 1 : 0;
+}
+
 // rows per output tile of the variant stil_gemm_nt picks for [M,N] (the granularity of `colstats`)
 extern "C" int stil_gemm_nt_tile_rows(int M, int N, int tune) { const int v = stil_gemm_nt_variant(M, N, tune); return (v == 11 || v == 12) ? 64 : 128; }
 
@@ -806,7 +872,8 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
                             int pad_x, int mode, int out_stride, int out_py, int out_px, int out_OH, int out_OW,
                             const float* bias, const float* sub, const float* scale,
                             const float* shift, const float* resid, int ldr, float* pre, int act, float alpha,
-                            float* colstats, const float* a_bn, const float* relu_mask, int ldm, int tune_arg, void* stream) {
+                            float* colstats, const float* a_bn, const float* relu_mask, int ldm,
+                            const float* bs_y, const float* bs_stats, float* bstats, int bs_relu, int bs_tile0, int tune_arg, void* stream) {
   const int tune = tune_arg % 10000;                 // + 10000: scalar (one dword per lane) epilogue, for A/B measurements and tests
   const bool scalar_epilogue = tune_arg / 10000 == 1;
   STIL_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0, "stil_gemm_nt: null pointer or empty shape (M=%d N=%d K=%d)", M, N, K);
@@ -829,6 +896,11 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
     p.wide = (N % 4 == 0) && (ldc % 4 == 0) && (!resid || ldr % 4 == 0) && (!relu_mask || ldm % 4 == 0) && al16(relu_mask) && al16(C) && al16(resid) && al16(pre) && al16(bias) && al16(sub) &&
              al16(scale) && al16(shift) && !scalar_epilogue ? 1 : 0;
   }
+  p.bs_y = bs_y; p.bs_stats = bs_stats; p.bstats = bstats; p.ldbs = ldc; p.bs_relu = bs_relu; p.bs_tile0 = bs_tile0;
+  STIL_REQUIRE(!bstats || (bs_y && bs_stats && (bs_relu == 0 || bs_relu == 2) && bs_tile0 >= 0 && !colstats && !a_bn && p.wide &&
+                           ((uintptr_t)bs_y % 16) == 0 && ((uintptr_t)bs_stats % 16) == 0 && (tune % 100 == 0 || tune % 100 == 11)),
+               "stil_gemm_nt: bstats needs bs_y / bs_stats, bs_relu 0 or 2, the 16-byte epilogue on 64x64 tiles (stil_gemm_nt_bstats_ok) "
+               "and excludes colstats / a_bn");
   STIL_REQUIRE(!colstats || (p.os == 1 && !bias && !sub && !scale && !shift && !resid && act == 0),
                "stil_gemm_nt: colstats describes the raw product (no bias / affine / residual / activation / output map)");
   p.vecA = is_vec(A, lda) && (srcC % 4 == 0);
@@ -847,8 +919,9 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   rc = gemm_nt_attr();
   if (rc) return rc;
   if (a_bn) {   // BatchNorm + ReLU of the producing layer applied while A is staged: 64x64 tiles, vector loads, BK = 16 only
-    STIL_REQUIRE(vec && !bk32 && mode == 0 && srcC % 16 == 0 && srcC <= 2048 && (variant == 11 || tune % 100 == 0),
-                 "stil_gemm_nt: a_bn needs 16-byte aligned operands, a forward gather, Cin %% 16 == 0 and Cin <= 2048 (Cin=%d)", srcC);
+    STIL_REQUIRE(vec && !bk32 && mode == 0 && srcC % 16 == 0 && srcC <= 2048 && (tune % 100 == 0 || tune % 100 == 11),
+                 "stil_gemm_nt: a_bn runs 64x64 tiles only (tune %% 100 must be 0 or 11: the caller sizes colstats by "
+                 "stil_gemm_nt_tile_rows) and needs 16-byte aligned operands, a forward gather, Cin %% 16 == 0 and Cin <= 2048 (Cin=%d)", srcC);
     const dim3 grid_(cdiv(M, 64) * cdiv(N, 64));
     const size_t lds_ = (size_t)2 * 64 * 2 * 20 * sizeof(float) + (size_t)3 * srcC * sizeof(float);
     if (acc2 && plain) hipLaunchKernelGGL((gemm_nt_kernel<1, 1, 16, true, true, true, true>), grid_, dim3(256), lds_, s, p);

@@ -57,7 +57,7 @@ def set_teacher_pipe(pipe: Optional[TeacherPipe]):
 
 
 def _conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool, train: bool, resid=None, stem=None, passthrough=False, defer=False,
-             xstats=None, premask_in=None, premask_out=None, rstats=None):
+             xstats=None, premask_in=None, premask_out=None, rstats=None, bstat_send=None, bstat_recv=None):
     """passthrough (first conv of a residual block): -> (out, alias of x) so the identity branch's gradient is folded
     into this conv's input-gradient GEMM (ops.ConvBnActFn).
     defer (training, inner layers of a block): -> (..., stats) with out = the RAW conv output; the next conv gets them as
@@ -68,7 +68,7 @@ def _conv_bn(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool, train: bool, re
     if train:
         out = ops.ConvBnActFn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                     bn.num_batches_tracked, resid, k, stride, pad, relu, stem, passthrough, defer, xstats,
-                                    premask_in, premask_out, rstats)
+                                    premask_in, premask_out, rstats, bstat_send, bstat_recv)
         if pipe is not None:
             pipe.published()
         return out
@@ -100,14 +100,18 @@ class Bottleneck(nn.Module):  # models/resnets.py:91-132
         pm = train and ops._PREMASK
         cin = getattr(x, "_stil_premask", None) if pm else None   # x is the previous block's relu output: hand its gradient back masked
         cout = {} if pm else None
+        # BatchNorm-backward sums ride in the consumer's input-gradient GEMM (ops.ConvBnActFn bstat_send / bstat_recv): one cell
+        # per conv+BN layer with a single consumer conv -- bn1 -> conv2, bn2 -> conv3, bn3 (block output) -> the next block's conv1
+        bin_ = getattr(x, "_stil_bstat", None) if train else None
+        b1, b2, b3 = ({}, {}, {}) if train else (None, None, None)
         if d1:
-            out, identity, st1 = _conv_bn(x, self.conv1, self.bn1, True, train, passthrough=True, defer=True, premask_in=cin)
+            out, identity, st1 = _conv_bn(x, self.conv1, self.bn1, True, train, passthrough=True, defer=True, premask_in=cin, bstat_send=bin_, bstat_recv=b1)
         else:
-            out, identity = _conv_bn(x, self.conv1, self.bn1, True, train, passthrough=True, premask_in=cin)
+            out, identity = _conv_bn(x, self.conv1, self.bn1, True, train, passthrough=True, premask_in=cin, bstat_send=bin_)
         if d2:
-            out, st2 = _conv_bn(out, self.conv2, self.bn2, True, train, defer=True, xstats=st1)
+            out, st2 = _conv_bn(out, self.conv2, self.bn2, True, train, defer=True, xstats=st1, bstat_send=b1, bstat_recv=b2)
         else:
-            out = _conv_bn(out, self.conv2, self.bn2, True, train, xstats=st1)
+            out = _conv_bn(out, self.conv2, self.bn2, True, train, xstats=st1, bstat_send=b1)
         rst = None
         if self.downsample is not None:
             if train and ops.can_defer_bn(self.downsample[0].out_channels):   # the shortcut's BatchNorm is applied inside bn3's pass
@@ -115,9 +119,11 @@ class Bottleneck(nn.Module):  # models/resnets.py:91-132
             else:
                 identity = _conv_bn(identity, self.downsample[0], self.downsample[1], False, train)
         Nb, H, W, C = identity.shape
-        out = _conv_bn(out, self.conv3, self.bn3, True, train, resid=identity.reshape(Nb * H * W, C), xstats=st2, premask_out=cout, rstats=rst)
+        out = _conv_bn(out, self.conv3, self.bn3, True, train, resid=identity.reshape(Nb * H * W, C), xstats=st2, premask_out=cout, rstats=rst,
+                       bstat_send=b2, bstat_recv=b3)
         if cout is not None:
             out._stil_premask = cout   # the next block's first conv (the only consumer of `out`) picks it up
+            out._stil_bstat = b3
         return out
 
 
@@ -137,10 +143,12 @@ class BasicBlock(nn.Module):  # models/resnets.py:50-88
         pm = train and ops._PREMASK
         cin = getattr(x, "_stil_premask", None) if pm else None
         cout = {} if pm else None
+        bin_ = getattr(x, "_stil_bstat", None) if train else None
+        b1, b2 = ({}, {}) if train else (None, None)
         if train and ops.can_defer_bn(self.conv1.out_channels):     # bn1 + relu applied inside conv2's operand staging
-            out, identity, st1 = _conv_bn(x, self.conv1, self.bn1, True, train, passthrough=True, defer=True, premask_in=cin)
+            out, identity, st1 = _conv_bn(x, self.conv1, self.bn1, True, train, passthrough=True, defer=True, premask_in=cin, bstat_send=bin_, bstat_recv=b1)
         else:
-            out, identity = _conv_bn(x, self.conv1, self.bn1, True, train, passthrough=True, premask_in=cin)
+            out, identity = _conv_bn(x, self.conv1, self.bn1, True, train, passthrough=True, premask_in=cin, bstat_send=bin_)
         rst = None
         if self.downsample is not None:
             if train and ops.can_defer_bn(self.downsample[0].out_channels):
@@ -148,9 +156,11 @@ class BasicBlock(nn.Module):  # models/resnets.py:50-88
             else:
                 identity = _conv_bn(identity, self.downsample[0], self.downsample[1], False, train)
         Nb, H, W, C = identity.shape
-        out = _conv_bn(out, self.conv2, self.bn2, True, train, resid=identity.reshape(Nb * H * W, C), xstats=st1, premask_out=cout, rstats=rst)
+        out = _conv_bn(out, self.conv2, self.bn2, True, train, resid=identity.reshape(Nb * H * W, C), xstats=st1, premask_out=cout, rstats=rst,
+                       bstat_send=b1, bstat_recv=b2)
         if cout is not None:
             out._stil_premask = cout
+            out._stil_bstat = b2
         return out
 
 

@@ -163,10 +163,13 @@ def _grad_into(param: torch.Tensor, writer):
 
 # ------------------------------------------------------------------------------------------ raw wrappers
 def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None, bias=None, sub=None, scale=None, shift=None,
-            resid=None, pre=None, act=0, alpha=1.0, pads=None, outmap=None, out_rows=None, colstats=None, a_bn=None, relu_mask=None):
+            resid=None, pre=None, act=0, alpha=1.0, pads=None, outmap=None, out_rows=None, colstats=None, a_bn=None, relu_mask=None,
+            bstats=None):
     """C = epilogue(alpha * Agather . W^T).  geom = (srcH, srcW, srcC, OH, OW, KH, KW, stride, pad, mode);
     pads = (pad_y, pad_x) overrides geom's pad; outmap = (out_stride, py, px, out_OH, out_OW) scatters GEMM row
-    (n, oy, ox) to output row (n*out_OH + oy*s + py)*out_OW + ox*s + px (out_rows = rows of `out` then)."""
+    (n, oy, ox) to output row (n*out_OH + oy*s + py)*out_OW + ox*s + px (out_rows = rows of `out` then).
+    bstats = (y, stats, partials, relu_mode, tile0): the epilogue also leaves the BatchNorm-backward partial sums of the layer
+    whose output gradient this launch produces (include/stil_hip.h `bstats`)."""
     if geom is None:
         geom = (1, 1, K, 1, 1, 1, 1, 1, 0, 0)
     pads = (geom[8], geom[8]) if pads is None else pads
@@ -189,7 +192,9 @@ def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None,
     L.gemm_nt(_p(A), _p(W), _p(out), M, N, K, lda, ldb, ldc, *geom[:8], pads[0], pads[1], geom[9], *outmap,
               _p(bias), _p(sub), _p(scale), _p(shift), _p(resid),
               (ldc if resid is not None else 0), _p(pre), act, float(alpha), _p(colstats), _p(a_bn), _p(relu_mask),
-              (ldc if relu_mask is not None else 0), TUNE["gemm"], _stream(), meta=meta)
+              (ldc if relu_mask is not None else 0), *((_p(bstats[0]), _p(bstats[1]), _p(bstats[2]), int(bstats[3]), int(bstats[4]))
+                                                       if bstats is not None else (None, None, None, 0, 0)),
+              TUNE["gemm"], _stream(), meta=meta)
     return out
 
 
@@ -338,6 +343,7 @@ _BN_EPILOGUE_STATS = __import__("os").environ.get("STIL_BN_EPILOGUE_STATS", "1")
 
 _BN_DEFER = __import__("os").environ.get("STIL_BN_DEFER", "1") != "0"
 _PREMASK = __import__("os").environ.get("STIL_PREMASK", "1") != "0"   # residual gradients leave the next block's dgrad GEMM pre-masked
+_BN_BWD_EPILOGUE = __import__("os").environ.get("STIL_BN_BWD_EPILOGUE", "1") != "0"   # BatchNorm-backward sums in the producing GEMM's epilogue
 
 
 def can_defer_bn(Cout: int) -> bool:
@@ -355,7 +361,7 @@ class ConvBnActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, gamma, beta, rmean, rvar, nbt, resid, k, stride, pad, relu, stem, passthrough=False, defer=False, xstats=None,
-                premask_in=None, premask_out=None, rstats=None):
+                premask_in=None, premask_out=None, rstats=None, bstat_send=None, bstat_recv=None):
         """passthrough: also return x itself as a second output.  A residual block routes its identity branch through
         that alias, so the branch's gradient arrives HERE and is added inside the input-gradient GEMM's epilogue
         instead of by a separate accumulation kernel of the autograd engine.
@@ -369,7 +375,12 @@ class ConvBnActFn(torch.autograd.Function):
         publishes the dict, the NEXT block's first node -- the only consumer of z -- receives it.  That node's input-gradient
         GEMM then writes dL/dz already multiplied by the ReLU mask (z > 0), read in its 16-byte epilogue (stil_gemm_nt
         relu_mask), and says so in the dict; this node's BatchNorm backward then takes the gradient as it comes: it neither
-        reads z nor materialises the masked gradient for the identity branch (one wide-tensor pass fewer per block)."""
+        reads z nor materialises the masked gradient for the identity branch (one wide-tensor pass fewer per block).
+        bstat_recv / bstat_send (a shared dict per conv+BN layer whose output has ONE consumer conv): the layer publishes its raw
+        output y and statistics in bstat_recv; its consumer gets the same dict as bstat_send and, in backward, lets its
+        input-gradient GEMM's epilogue leave the layer's BatchNorm-backward partial sums (sum g', sum g' * xhat per 64-row tile:
+        stil_gemm_nt `bstats`) in the dict -- the layer's backward then skips the reduction pass over g and y
+        (stil_bn_train_bwd_tiles).  Falls back to the pass whenever the consumer could not fuse (no cell filled)."""
         _chk(x, w, gamma, beta, resid)
         ctx.set_materialize_grads(False)
         # deferred layers: the inner conv+BN+ReLU of a block (applied by the next conv's operand staging) and the shortcut's
@@ -426,6 +437,16 @@ class ConvBnActFn(torch.autograd.Function):
         ctx.has_alias = bool(passthrough)
         ctx.premask_in = premask_in if (stem is None and stride == 1) else None     # only the plain / stride-1 gather dgrad GEMMs mask
         ctx.premask_out = premask_out if (relu and resid is not None and not defer) else None
+        ctx.bstat_send = bstat_send if (_BN_BWD_EPILOGUE and stem is None) else None
+        ctx.bstat_recv = None
+        if _BN_BWD_EPILOGUE and bstat_recv is not None and Cout % 4 == 0:
+            # mode 2: inner layer (ReLU mask recomputed from y); mode 0: block output whose gradient arrives pre-masked
+            if defer and relu and resid is None:
+                bstat_recv.update(y=y, stats=stats, mode=2)
+                ctx.bstat_recv = bstat_recv
+            elif relu and resid is not None and not defer and premask_out is not None:
+                bstat_recv.update(y=y, stats=stats, mode=0, premask=premask_out)
+                ctx.bstat_recv = bstat_recv
         out = (y if defer else z).view(Nb, OH, OW, Cout)
         if defer:
             ctx.mark_non_differentiable(stats)
@@ -454,8 +475,19 @@ class ConvBnActFn(torch.autograd.Function):
         dgamma = gslot if gslot is not None else torch.empty_like(gamma)
         dbeta = bslot if bslot is not None else torch.empty_like(beta)
         acc = 1 if gslot is not None else 0
-        lib().bn_train_bwd(_p(gz), _p(z), _p(y), _p(gamma), _p(stats), _p(dy), _p(gres), _p(dgamma), _p(dbeta), _p(coef), M,
-                           Cout, 0 if premasked else ((1 if has_res else 2) if relu else 0), acc, _p(ws), nb, _stream())
+        relu_mode = 0 if premasked else ((1 if has_res else 2) if relu else 0)
+        cell = ctx.bstat_recv
+        part = cell.get("part") if cell is not None else None
+        if part is not None and gres is None and tuple(part.shape) == (2 * cell["nt"], Cout) and (cell["mode"] == 2) == (relu_mode == 2) \
+                and (cell["mode"] != 0 or premasked):
+            # the consumer's input-gradient GEMM left the per-tile sums: no reduction pass over gz and y
+            nb2 = lib().bn_bwd_tiles_workspace_bytes(cell["nt"], Cout)
+            ws2 = _ws.get(nb2 + 8, dev)
+            lib().bn_train_bwd_tiles(_p(gz), _p(z), _p(y), _p(gamma), _p(stats), _p(part), cell["nt"], _p(dy), _p(dgamma), _p(dbeta), _p(coef), M,
+                                     Cout, relu_mode, acc, _p(ws2), nb2, _stream())
+        else:
+            lib().bn_train_bwd(_p(gz), _p(z), _p(y), _p(gamma), _p(stats), _p(dy), _p(gres), _p(dgamma), _p(dbeta), _p(coef), M,
+                               Cout, relu_mode, acc, _p(ws), nb, _stream())
         if gslot is not None:
             _touch(gamma)
             _touch(beta)
@@ -478,31 +510,58 @@ class ConvBnActFn(torch.autograd.Function):
                 zmask = x.view(Nb * H * W_, Cin) if cell is not None else None
                 if cell is not None:
                     cell["masked"] = True   # both stride-1 branches below apply the mask
+                # BatchNorm-backward partial sums of the layer that produced x, left by this GEMM's epilogue (bstat_send)
+                bs = None
+                sc_ = ctx.bstat_send
+                Min = Nb * H * W_
+                if sc_ is not None and "y" in sc_ and Cin % 4 == 0 and (sc_["mode"] == 2 or (zmask is not None and sc_.get("premask") is cell)) \
+                        and (stride == 1 or ga is None) and tuple(sc_["y"].shape) == (Min, Cin) \
+                        and lib().gemm_nt_bstats_ok(None, Cin, Cin, _p(ga), Cin, _p(zmask), Cin, _p(sc_["y"])):
+                    nt_ = _bstat_tiles(Nb, H, W_, k, stride, pad)
+                    bs = (sc_["y"], sc_["stats"], torch.empty((2 * nt_, Cin), dtype=torch.float32, device=dev), sc_["mode"], 0)
                 if k == 1 and stride == 1:
                     wd = cached_layout(w, "_stil_wd")  # [Cin, Cout]
                     if wd is None:
                         wd = transpose(w.reshape(Cout, Cin))
-                    dx = gemm_nt(dy, wd, M, Cin, Cout, resid=ga, relu_mask=zmask).view(Nb, H, W_, Cin)
+                    dx = gemm_nt(dy, wd, M, Cin, Cout, resid=ga, relu_mask=zmask, bstats=bs).view(Nb, H, W_, Cin)
                 elif stride == 1:
                     wd = cached_layout(w, "_stil_wd")
                     if wd is None:
                         wd = torch.empty((Cin, k * k * Cout), dtype=torch.float32, device=dev)
                         lib().conv_weight_layout(_p(w), None, _p(wd), Cout, Cin, k, k, _stream())
                     g2 = (OH, OW, Cout, H, W_, k, k, stride, pad, 1)
-                    dx = gemm_nt(dy, wd, Nb * H * W_, Cin, k * k * Cout, geom=g2, resid=ga, relu_mask=zmask).view(Nb, H, W_, Cin)
+                    dx = gemm_nt(dy, wd, Nb * H * W_, Cin, k * k * Cout, geom=g2, resid=ga, relu_mask=zmask, bstats=bs).view(Nb, H, W_, Cin)
                 else:
-                    dx = strided_dgrad(dy, w, Nb, H, W_, Cin, OH, OW, Cout, k, stride, pad)
+                    dx = strided_dgrad(dy, w, Nb, H, W_, Cin, OH, OW, Cout, k, stride, pad, bstats=bs)
                     if ga is not None:
                         axpby(dx.view(-1), ga.view(-1), 1.0, 1.0, out=dx.view(-1))
+                if bs is not None:
+                    sc_["part"], sc_["nt"] = bs[2], bs[2].shape[0] // 2
             elif gx_alias is not None:
                 dx = gx_alias
             gw = geom[:9]
             dw = wgrad_param(w, dy, x, M, Cout, k * k * Cin, geom=gw, x_bn=xstats)
         return (dx, dw, (None if gslot is not None else dgamma), (None if bslot is not None else dbeta), None, None, None,
-                dres, None, None, None, None, None, None, None, None, None, None, None)
+                dres, None, None, None, None, None, None, None, None, None, None, None, None, None)
 
 
-def strided_dgrad(dy, w, Nb, H, W_, Cin, OH, OW, Cout, k, stride, pad):
+def _bstat_tiles(Nb, H, W_, k, stride, pad):
+    """64-row tiles of the input-gradient launch(es) of a conv over an [Nb, H, W_] input: one launch for stride 1, one per
+    tap-owning output phase otherwise (strided_dgrad) -- the row count of a `bstats` partial array is twice this."""
+    if stride == 1:
+        return (Nb * H * W_ + 63) // 64
+    n = 0
+    for py in range(stride):
+        if len(range((py + pad) % stride, k, stride)) == 0 or len(range(py, H, stride)) == 0:
+            continue
+        for px in range(stride):
+            if len(range((px + pad) % stride, k, stride)) == 0 or len(range(px, W_, stride)) == 0:
+                continue
+            n += (Nb * len(range(py, H, stride)) * len(range(px, W_, stride)) + 63) // 64
+    return n
+
+
+def strided_dgrad(dy, w, Nb, H, W_, Cin, OH, OW, Cout, k, stride, pad, bstats=None):
     """Input gradient of a stride-s conv as s*s stride-1 gathers, one per output phase (py, px): phase pixels
     (s*oy'+py, s*ox'+px) only see taps ky = ky0 + s*j with ky0 = (py+pad) % s, so no multiply-by-zero work is done
     (the generic mode-1 gather computes s*s times the algorithmic MACs)."""
@@ -510,6 +569,7 @@ def strided_dgrad(dy, w, Nb, H, W_, Cin, OH, OW, Cout, k, stride, pad):
     # every output pixel belongs to exactly one phase; phases without taps (1x1 s2: 3 of 4) must read as zero
     all_covered = all(len(range((p_ + pad) % stride, k, stride)) > 0 for p_ in range(stride))
     dx = (torch.empty if all_covered else torch.zeros)((Nb * H * W_, Cin), dtype=torch.float32, device=dev)
+    tile0 = 0    # bstats: the phases fill consecutive tile ranges of ONE partial array (pixels no phase owns have a zero gradient)
     for py in range(stride):
         ky0 = (py + pad) % stride
         KHs = len(range(ky0, k, stride))
@@ -531,7 +591,8 @@ def strided_dgrad(dy, w, Nb, H, W_, Cin, OH, OW, Cout, k, stride, pad):
             # iy = oy' + dy0 - jy = oy' - pad' + ky'  with ky' = KHs-1-jy, pad' = KHs-1-dy0
             geom = (OH, OW, Cout, Hs, Ws, KHs, KWs, 1, 0, 0)
             gemm_nt(dy, wsub, Nb * Hs * Ws, Cin, KHs * KWs * Cout, geom=geom, out=dx, pads=(KHs - 1 - dy0, KWs - 1 - dx0),
-                    outmap=(stride, py, px, H, W_))
+                    outmap=(stride, py, px, H, W_), bstats=None if bstats is None else (*bstats[:4], tile0))
+            tile0 += (Nb * Hs * Ws + 63) // 64
     return dx.view(Nb, H, W_, Cin)
 
 

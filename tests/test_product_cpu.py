@@ -33,7 +33,7 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     from stil_tta_amd._lib import lib
     L = lib()
     with pytest.raises(RuntimeError, match="null pointer"):
-        L.gemm_nt(None, None, None, 4, 4, 4, 4, 4, 4, 1, 1, 4, 1, 1, 1, 1, 1, 0, 0, 0, 1, 0, 0, 1, 1, None, None, None, None, None, 0, None, 0, 1.0, None, None, None, 0, 0, None)
+        L.gemm_nt(None, None, None, 4, 4, 4, 4, 4, 4, 1, 1, 4, 1, 1, 1, 1, 1, 0, 0, 0, 1, 0, 0, 1, 1, None, None, None, None, None, 0, None, 0, 1.0, None, None, None, 0, None, None, None, 0, 0, 0, None)
     with pytest.raises(RuntimeError, match="multiple of 4"):
         L.ema_update(ctypes.c_void_p(16), ctypes.c_void_p(32), 6, 0.9, None)
     assert L.wgrad_workspace_bytes(1 << 20, 64, 576, 0) > 0
@@ -278,6 +278,43 @@ def test_overlapped_gradient_exchange_and_autograd_collectives_world2_gloo():
     weights, late contributions refused), comm.AllGatherFn and the one-message buffer broadcast, two gloo ranks."""
     res = _run_ranks(_exchange_worker)
     assert res == {0: True, 1: True}
+
+
+def _mismatch_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    from stil_tta_amd.comm import GradExchange
+    from stil_tta_amd.driver import init_distributed
+    init_distributed(backend="gloo", timeout_s=20)
+    flat = _FakeFlat([3000, 500, 5000, 700], gap_after=None)
+    ex = GradExchange(flat, bucket_elems=4096)
+    for step in range(2):                       # both ranks learn and agree the plan of ("sig",), then overlap once
+        ex.begin(("sig",))
+        for t in flat.tensors:
+            ex.note(t)
+        ex.finish()
+    if rank == 1:
+        del ex.plans[("sig",)]                  # rank 1 falls back to LEARNING mode under the same signature: a mode mismatch
+    t0 = time.time()
+    what = "no exception"
+    try:
+        ex.begin(("sig",))
+        for t in flat.tensors:
+            ex.note(t)                          # rank 0 (overlap mode) launches bucket all-reduces its peer will never match
+        ex.finish()                             # rank 1 (learning step) verifies at once and raises before issuing anything
+        ex.begin(("sig",))                      # rank 0 would raise here at the latest
+    except Exception as e:                      # noqa: BLE001 -- rank 0 may also die of its peer's closed connection
+        what = f"{type(e).__name__}: {e}"
+    q.put((rank, (what, time.time() - t0)))
+
+
+def test_mode_mismatch_terminates_both_ranks_world2_gloo():
+    """Round-3 advisor: a rank in overlap mode has already launched bucket all-reduces when its learning-mode peer raises and
+    never matches them.  Both ranks must TERMINATE with an exception -- the learning rank with the named disagreement at once,
+    the overlap rank no later than the process-group timeout -- instead of one of them waiting in a collective forever."""
+    res = _run_ranks(_mismatch_worker, timeout=120)
+    assert "disagree on the gradient exchange" in res[1][0] and res[1][1] < 15, res
+    assert res[0][0] != "no exception" and res[0][1] < 60, res
 
 
 # ---------------------------------------------------------------- the run.py config surface (SURVEY.md 8b)
