@@ -48,7 +48,10 @@ int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, 
                  const float* bias, const float* sub, const float* scale, const float* shift, const float* resid,
                  int ldr, float* pre, int act, float alpha, float* colstats, const float* a_bn, const float* relu_mask, int ldm,
                  const float* bs_y, const float* bs_stats, float* bstats, int bs_relu, int bs_tile0,
-                 int tune, void* stream);
+                 const float* scale_var, float var_eps, int tune, void* stream);
+/* `scale_var` (optional, needs `scale`): the per-column scale is scale[n] / sqrtf(scale_var[n] + var_eps) -- an eval-mode BatchNorm
+ *   folded into the conv epilogue straight from (weight, bias, running_mean, running_var): sub = running_mean, scale = weight,
+ *   scale_var = running_var, shift = bias, formed exactly as stil_bn_eval_affine forms it (models/resnets.py:112-132 in eval mode). */
 /* `bstats` (optional; 64x64 tiles with the 16-byte epilogue: stil_gemm_nt_bstats_ok): this launch produces the gradient g w.r.t.
  *   the output z = [relu](BN(y)) of a training conv+BN layer (it is the input-gradient GEMM of that layer's consumer).  The
  *   epilogue then also leaves the BatchNorm-BACKWARD partial sums of that layer, per 64-row tile t = bs_tile0 + tile index:

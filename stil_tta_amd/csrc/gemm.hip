@@ -35,6 +35,8 @@ struct GemmNTArgs {
   const float* bias;
   const float* sub;    // per-column subtrahend (eval BatchNorm running mean)
   const float* scale;
+  const float* var;    // optional: scale[n] is divided by sqrtf(var[n] + var_eps) -- eval BatchNorm's a = gamma / sqrt(running_var + eps)
+  float var_eps;       // formed here exactly as bn_eval_affine_kernel forms it (one launch per layer and step fewer)
   const float* shift;
   const float* resid;
   int ldr;
@@ -174,7 +176,12 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNTArgs& p, f32x16 (&a
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f), one4 = make_float4(1.f, 1.f, 1.f, 1.f);
         const float4 bia = p.bias ? *reinterpret_cast<const float4*>(p.bias + col) : zero4;
         const float4 sb = p.sub ? *reinterpret_cast<const float4*>(p.sub + col) : zero4;
-        const float4 sc = p.scale ? *reinterpret_cast<const float4*>(p.scale + col) : one4;
+        float4 sc = p.scale ? *reinterpret_cast<const float4*>(p.scale + col) : one4;
+        if (p.var) {
+          const float4 vv = *reinterpret_cast<const float4*>(p.var + col);
+          sc.x = sc.x / sqrtf(vv.x + p.var_eps); sc.y = sc.y / sqrtf(vv.y + p.var_eps);
+          sc.z = sc.z / sqrtf(vv.z + p.var_eps); sc.w = sc.w / sqrtf(vv.w + p.var_eps);
+        }
         const float4 sh = p.shift ? *reinterpret_cast<const float4*>(p.shift + col) : zero4;
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
@@ -264,7 +271,8 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNTArgs& p, f32x16 (&a
     if (col >= p.N) continue;
     const float bia = p.bias ? p.bias[col] : 0.f;
     const float sb = p.sub ? p.sub[col] : 0.f;
-    const float sc = p.scale ? p.scale[col] : 1.f;
+    float sc = p.scale ? p.scale[col] : 1.f;
+    if (p.var) sc = sc / sqrtf(p.var[col] + p.var_eps);
     const float sh = p.shift ? p.shift[col] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -873,7 +881,8 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
                             const float* bias, const float* sub, const float* scale,
                             const float* shift, const float* resid, int ldr, float* pre, int act, float alpha,
                             float* colstats, const float* a_bn, const float* relu_mask, int ldm,
-                            const float* bs_y, const float* bs_stats, float* bstats, int bs_relu, int bs_tile0, int tune_arg, void* stream) {
+                            const float* bs_y, const float* bs_stats, float* bstats, int bs_relu, int bs_tile0,
+                            const float* scale_var, float var_eps, int tune_arg, void* stream) {
   const int tune = tune_arg % 10000;                 // + 10000: scalar (one dword per lane) epilogue, for A/B measurements and tests
   const bool scalar_epilogue = tune_arg / 10000 == 1;
   STIL_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0, "stil_gemm_nt: null pointer or empty shape (M=%d N=%d K=%d)", M, N, K);
@@ -885,6 +894,8 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   p.A = A; p.Bw = W; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.g = ConvGeom{srcH, srcW, srcC, OH, OW, KH, KW, stride, pad_y, pad_x, mode};
   p.os = out_stride < 1 ? 1 : out_stride; p.opy = out_py; p.opx = out_px; p.oOH = out_OH; p.oOW = out_OW;
+  p.var = scale_var; p.var_eps = var_eps;
+  STIL_REQUIRE(!scale_var || scale, "stil_gemm_nt: scale_var divides `scale`, which is missing");
   p.bias = bias; p.sub = sub; p.scale = scale; p.shift = shift; p.resid = resid; p.ldr = ldr; p.pre = pre; p.act = act;
   p.alpha = alpha;
   p.colstats = colstats;
@@ -894,7 +905,7 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   {
     auto al16 = [](const void* q) { return q == nullptr || ((uintptr_t)q % 16) == 0; };
     p.wide = (N % 4 == 0) && (ldc % 4 == 0) && (!resid || ldr % 4 == 0) && (!relu_mask || ldm % 4 == 0) && al16(relu_mask) && al16(C) && al16(resid) && al16(pre) && al16(bias) && al16(sub) &&
-             al16(scale) && al16(shift) && !scalar_epilogue ? 1 : 0;
+             al16(scale) && al16(scale_var) && al16(shift) && !scalar_epilogue ? 1 : 0;
   }
   p.bs_y = bs_y; p.bs_stats = bs_stats; p.bstats = bstats; p.ldbs = ldc; p.bs_relu = bs_relu; p.bs_tile0 = bs_tile0;
   STIL_REQUIRE(!bstats || (bs_y && bs_stats && (bs_relu == 0 || bs_relu == 2) && bs_tile0 >= 0 && !colstats && !a_bn && p.wide &&

@@ -164,7 +164,7 @@ def _grad_into(param: torch.Tensor, writer):
 # ------------------------------------------------------------------------------------------ raw wrappers
 def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None, bias=None, sub=None, scale=None, shift=None,
             resid=None, pre=None, act=0, alpha=1.0, pads=None, outmap=None, out_rows=None, colstats=None, a_bn=None, relu_mask=None,
-            bstats=None):
+            bstats=None, scale_var=None, var_eps=0.0):
     """C = epilogue(alpha * Agather . W^T).  geom = (srcH, srcW, srcC, OH, OW, KH, KW, stride, pad, mode);
     pads = (pad_y, pad_x) overrides geom's pad; outmap = (out_stride, py, px, out_OH, out_OW) scatters GEMM row
     (n, oy, ox) to output row (n*out_OH + oy*s + py)*out_OW + ox*s + px (out_rows = rows of `out` then).
@@ -194,7 +194,7 @@ def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None,
               (ldc if resid is not None else 0), _p(pre), act, float(alpha), _p(colstats), _p(a_bn), _p(relu_mask),
               (ldc if relu_mask is not None else 0), *((_p(bstats[0]), _p(bstats[1]), _p(bstats[2]), int(bstats[3]), int(bstats[4]))
                                                        if bstats is not None else (None, None, None, 0, 0)),
-              TUNE["gemm"], _stream(), meta=meta)
+              _p(scale_var), float(var_eps), TUNE["gemm"], _stream(), meta=meta)
     return out
 
 
@@ -597,15 +597,15 @@ def strided_dgrad(dy, w, Nb, H, W_, Cin, OH, OW, Cout, k, stride, pad, bstats=No
 
 
 def conv_bn_eval(x, w, gamma, beta, rmean, rvar, resid, k, stride, pad, relu, stem=None):
-    """Teacher path: eval-mode BN folded into the conv epilogue (no grad)."""
+    """Teacher path: eval-mode BN folded into the conv epilogue (no grad): (y - running_mean) * (weight / sqrt(running_var + eps)) + bias,
+    the scale formed in the epilogue itself (stil_gemm_nt scale_var) -- no per-layer affine kernel."""
     Cout = w.shape[0]
     dev = x.device
-    ab = torch.empty((3, Cout), dtype=torch.float32, device=dev)
-    lib().bn_eval_affine(_p(gamma), _p(beta), _p(rmean), _p(rvar), _p(ab), Cout, 1e-5, _stream())
+    bn = dict(sub=rmean, scale=gamma, scale_var=rvar, var_eps=1e-5, shift=beta)
     if stem is not None:
         Nb, OH, OW, Kp, wpad = stem
         M = Nb * OH * OW
-        z = gemm_nt(x, wpad, M, Cout, Kp, sub=ab[2], scale=ab[0], shift=ab[1], resid=resid, act=1 if relu else 0)
+        z = gemm_nt(x, wpad, M, Cout, Kp, resid=resid, act=1 if relu else 0, **bn)
         return z.view(Nb, OH, OW, Cout)
     Nb, H, W_, Cin = x.shape
     OH = (H + 2 * pad - k) // stride + 1
@@ -618,8 +618,7 @@ def conv_bn_eval(x, w, gamma, beta, rmean, rvar, resid, k, stride, pad, relu, st
         if wf is None:
             wf = torch.empty((Cout, k * k * Cin), dtype=torch.float32, device=dev)
             lib().conv_weight_layout(_p(w), _p(wf), None, Cout, Cin, k, k, _stream())
-    z = gemm_nt(x, wf, M, Cout, k * k * Cin, geom=_conv_geom_fwd(H, W_, Cin, OH, OW, k, stride, pad), sub=ab[2], scale=ab[0],
-                shift=ab[1], resid=resid, act=1 if relu else 0)
+    z = gemm_nt(x, wf, M, Cout, k * k * Cin, geom=_conv_geom_fwd(H, W_, Cin, OH, OW, k, stride, pad), resid=resid, act=1 if relu else 0, **bn)
     return z.view(Nb, OH, OW, Cout)
 
 

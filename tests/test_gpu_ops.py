@@ -249,8 +249,8 @@ def test_premasked_residual_gradient_and_deferred_bn_equal_the_plain_blocks(ops,
     relu_mask).  Against the same blocks with both switched off: outputs, BN buffers and every parameter gradient bit for bit."""
     from stil_tta_amd.modules import ResNet
     res = []
-    for fused in (True, False):
-        ops._BN_DEFER, ops._PREMASK = fused, fused
+    for fused, bstat in ((True, False), (False, False), (True, True)):
+        ops._BN_DEFER, ops._PREMASK, ops._BN_BWD_EPILOGUE = fused, fused, bstat
         try:
             torch.manual_seed(5)
             net = ResNet(arch).cuda()
@@ -266,10 +266,78 @@ def test_premasked_residual_gradient_and_deferred_bn_equal_the_plain_blocks(ops,
             bufs = [b for blk in blocks for b in blk.buffers()]
             res.append([h.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in ps] + [b.clone() for b in bufs])
         finally:
-            ops._BN_DEFER, ops._PREMASK = True, True
-    assert len(res[0]) == len(res[1]) > 20
-    for i, (u, v) in enumerate(zip(*res)):
+            ops._BN_DEFER, ops._PREMASK, ops._BN_BWD_EPILOGUE = True, True, True
+    assert len(res[0]) == len(res[1]) == len(res[2]) > 20
+    for i, (u, v) in enumerate(zip(res[0], res[1])):
         assert torch.equal(u, v), f"tensor {i}: fused blocks differ from the plain ones (max |d| = {float((u.float() - v.float()).abs().max()):.3e})"
+    # ... and with the BatchNorm-backward sums left by the input-gradient GEMMs' epilogues (stil_gemm_nt bstats: per-tile fp32 sums
+    # combined in double, instead of a reduction pass of its own): the forward and the buffers are untouched, the gradients agree to
+    # rounding (the sums are added in another order -- and more accurately)
+    nfw = 2 + len(ps)
+    assert torch.equal(res[2][0], res[1][0]) and all(torch.equal(u, v) for u, v in zip(res[2][nfw:], res[1][nfw:]))
+    worst = 0.0
+    for i, (u, v) in enumerate(zip(res[2][1:nfw], res[1][1:nfw])):
+        d = float((u - v).abs().max()) / (1e-30 + float(v.abs().max()))
+        worst = max(worst, d)
+        assert d <= 2e-5, f"gradient {i}: epilogue BatchNorm-backward sums differ from the pass by {d:.2e} of the tensor's scale"
+    print(f"epilogue BN-backward sums vs the reduction pass: worst |d| / max|g| over {nfw - 1} gradients = {worst:.2e}")
+
+
+@pytest.mark.parametrize("M,N,K,mode,resid", [(64 * 5 + 17, 64, 96, 2, False), (1000, 128, 64, 0, True), (130, 256, 512, 2, True), (64, 64, 32, 0, False)])
+def test_gemm_epilogue_batchnorm_backward_sums(ops, M, N, K, mode, resid):
+    """stil_gemm_nt `bstats`: the per-tile sums of g' and g' * xhat the epilogue leaves (g' = the stored gradient, masked by the
+    recomputed ReLU sign for mode 2) against float64 sums over the same rows; stil_bn_train_bwd_tiles on them against
+    stil_bn_train_bwd's own reduction pass (dx, dgamma, dbeta)."""
+    from stil_tta_amd._lib import lib
+    from stil_tta_amd.ops import _p, _stream
+    g = torch.Generator().manual_seed(M + N)
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1
+    y = torch.randn(M, N, generator=g) * 2 + 0.3
+    R = torch.randn(M, N, generator=g) if resid else None
+    zmask = torch.randn(M, N, generator=g) if mode == 0 else None
+    mean, var = y.mean(0), y.var(0, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    gamma, beta = 0.5 + torch.rand(N, generator=g), 0.2 * torch.randn(N, generator=g)
+    stats = torch.stack([mean, rstd, gamma * rstd, beta]).contiguous()
+    nt = (M + 63) // 64
+    part = torch.full((2 * (nt + 3), N), float("nan"), device="cuda")
+    yd, sd_ = dev(y), dev(stats)
+    out = ops.gemm_nt(dev(A), dev(W), M, N, K, resid=None if R is None else dev(R), relu_mask=None if zmask is None else dev(zmask),
+                      bstats=(yd, sd_, part, mode, 3))
+    plain = ops.gemm_nt(dev(A), dev(W), M, N, K, resid=None if R is None else dev(R), relu_mask=None if zmask is None else dev(zmask))
+    assert torch.equal(out, plain) and bool(torch.isnan(part[:6]).all())        # same stored gradient; tiles before tile0 untouched
+    gd = out.cpu().double()
+    if mode == 2:
+        gd = gd * (((y - mean) * (gamma * rstd) + beta) > 0).double()
+    xhat = ((y - mean) * rstd).double()
+    got = part[6:].cpu().double().view(nt, 2, N)
+    for t in range(nt):
+        rows = slice(64 * t, min(M, 64 * t + 64))
+        s1, s2 = gd[rows].sum(0), (gd[rows] * xhat[rows]).sum(0)
+        sc = float((gd[rows].abs()).sum(0).max()) + 1.0
+        assert float((got[t, 0] - s1).abs().max()) <= 1e-5 * sc and float((got[t, 1] - s2).abs().max()) <= 2e-5 * sc * (1 + float(xhat.abs().max())), t
+    # the two BatchNorm backward entry points on the same gradient
+    L = lib()
+    gam = dev(gamma)
+    outs = []
+    for tiles in (False, True):
+        dx, coef = torch.empty(M, N, device="cuda"), torch.empty(3, N, device="cuda")
+        dga, dbe = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+        if tiles:
+            nb = L.bn_bwd_tiles_workspace_bytes(nt, N)
+            ws = torch.empty(nb + 16, dtype=torch.uint8, device="cuda")
+            L.bn_train_bwd_tiles(_p(out), None, _p(yd), _p(gam), _p(sd_), _p(part[6:]), nt, _p(dx), _p(dga), _p(dbe), _p(coef), M, N, mode, 0, _p(ws), nb, _stream())
+        else:
+            if N % 64:
+                continue
+            nb = L.bn_workspace_bytes(M, N)
+            ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+            L.bn_train_bwd(_p(out), None, _p(yd), _p(gam), _p(sd_), _p(dx), None, _p(dga), _p(dbe), _p(coef), M, N, mode, 0, _p(ws), nb, _stream())
+        outs.append((dx, dga, dbe))
+    for u, v in zip(*outs):
+        close(u, v, tol=1e-5, name="bn_train_bwd_tiles vs bn_train_bwd")
+    close(outs[1][2], gd.sum(0), tol=1e-5, name="dbeta vs float64")
+    close(outs[1][1], (gd * xhat).sum(0), tol=1e-5, name="dgamma vs float64")
 
 
 def test_stem_and_maxpool(ops):
