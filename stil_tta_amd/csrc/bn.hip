@@ -147,6 +147,43 @@ __global__ __launch_bounds__(256) void bn_tiles_stage2_kernel(const double* __re
   }
 }
 
+// Both stages in ONE launch when a single split covers every tile (nt <= 256: small per-GPU batches, where the step is bound by
+// its ~1300 dependent launches and not by bytes).  Same sums in the same order as stage 1 + stage 2 with nsplit = 1: identical bits.
+__global__ __launch_bounds__(256) void bn_tiles_fused_kernel(const float* __restrict__ ts, int nt, int tile_rows, int M, int C,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ rmean, float* __restrict__ rvar, long long* nbt,
+                                                              float* __restrict__ stats, float eps, float momentum) {
+  __shared__ double sh[3 * 8 * 32];
+  const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (c < C)
+    for (int t = lane; t < nt; t += 8) {
+      const double n = (double)min(tile_rows, M - t * tile_rows);
+      const double m = (double)ts[((long)t * 2) * C + c];
+      s1 += n * m; s2 += n * m * m; s3 += (double)ts[((long)t * 2 + 1) * C + c];
+    }
+  sh[lane * 32 + cl] = s1; sh[256 + lane * 32 + cl] = s2; sh[512 + lane * 32 + cl] = s3;
+  __syncthreads();
+  if (lane != 0 || c >= C) return;
+  double a = 0.0, b = 0.0, d = 0.0;
+  for (int l = 0; l < 8; ++l) { a += sh[l * 32 + cl]; b += sh[256 + l * 32 + cl]; d += sh[512 + l * 32 + cl]; }
+  double t1 = 0.0, t2 = 0.0, t3 = 0.0;   // stage 2's loop over its one split
+  t1 += a; t2 += b; t3 += d;
+  const double mean_d = t1 / (double)M;
+  double m2 = t3 + (t2 - t1 * mean_d);
+  const float mean = (float)mean_d;
+  const float var = fmaxf((float)(m2 / (double)M), 0.f);
+  const float rstd = 1.f / sqrtf(var + eps);
+  stats[c] = mean; stats[C + c] = rstd; stats[2 * C + c] = gamma[c] * rstd; stats[3 * C + c] = beta[c];
+  if (rmean) {
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+    const float unb = (M > 1) ? var * ((float)M / (float)(M - 1)) : var;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+  }
+}
+
 // eval mode: ab[0] = a = gamma / sqrt(running_var + eps), ab[1] = beta, ab[2] = running_mean.  The conv epilogue
 // applies (y - mean) * a + beta: the subtractive form keeps ATen's accuracy (no x*a - mean*a cancellation).
 __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -333,6 +370,36 @@ __global__ __launch_bounds__(256) void bn_bwd_tiles_final_kernel(const double* _
   coef[c] = gamma[c] * stats[C + c];
   coef[C + c] = s1 * invM;
   coef[2 * C + c] = s2 * invM;
+}
+
+// ... and in one launch when a single split covers every tile (see bn_tiles_fused_kernel): identical bits.
+__global__ __launch_bounds__(256) void bn_bwd_tiles_fused_kernel(const float* __restrict__ ts, int nt, int M, int C,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                  float* __restrict__ coef, int accumulate) {
+  __shared__ double sh[2 * 8 * 32];
+  const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int t = lane; t < nt; t += 8) {
+      s1 += (double)ts[((long)t * 2) * C + c];
+      s2 += (double)ts[((long)t * 2 + 1) * C + c];
+    }
+  sh[lane * 32 + cl] = s1; sh[256 + lane * 32 + cl] = s2;
+  __syncthreads();
+  if (lane != 0 || c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int l = 0; l < 8; ++l) { a += sh[l * 32 + cl]; b += sh[256 + l * 32 + cl]; }
+  double ta = 0.0, tb = 0.0;
+  ta += a; tb += b;
+  const float f1 = (float)ta, f2 = (float)tb;
+  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + f1 : f1;
+  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + f2 : f2;
+  const float invM = 1.f / (float)M;
+  coef[c] = gamma[c] * stats[C + c];
+  coef[C + c] = f1 * invM;
+  coef[2 * C + c] = f2 * invM;
 }
 
 // dx = gamma*rstd * (g - dbeta/M - xhat*dgamma/M)
@@ -548,12 +615,18 @@ extern "C" int stil_bn_train_fwd_tiles(const float* x, const float* tilestats, i
                "stil_bn_train_fwd_tiles: workspace too small or not 8-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const int nt = cdiv(M, tile_rows), nsplit = bn_tiles_nsplit(nt);
-  hipLaunchKernelGGL(bn_tiles_stage1_kernel, dim3(cdiv(C, 32), nsplit), dim3(256), 0, s, tilestats, nt, tile_rows, M, C,
-                     cdiv(nt, nsplit), (double*)workspace);
-  STIL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_tiles_stage2_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)workspace, nsplit, M, C, gamma, beta,
-                     running_mean, running_var, num_batches_tracked, stats, eps, momentum);
-  STIL_LAUNCH_CHECK();
+  if (nsplit == 1) {   // one launch: every tile fits one split
+    hipLaunchKernelGGL(bn_tiles_fused_kernel, dim3(cdiv(C, 32)), dim3(256), 0, s, tilestats, nt, tile_rows, M, C, gamma, beta,
+                       running_mean, running_var, num_batches_tracked, stats, eps, momentum);
+    STIL_LAUNCH_CHECK();
+  } else {
+    hipLaunchKernelGGL(bn_tiles_stage1_kernel, dim3(cdiv(C, 32), nsplit), dim3(256), 0, s, tilestats, nt, tile_rows, M, C,
+                       cdiv(nt, nsplit), (double*)workspace);
+    STIL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_tiles_stage2_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)workspace, nsplit, M, C, gamma, beta,
+                       running_mean, running_var, num_batches_tracked, stats, eps, momentum);
+    STIL_LAUNCH_CHECK();
+  }
   if (!z) return STIL_OK;   // statistics only: the consumer applies them while it stages its operand
   long total4 = (long)M * C / 4;
   int grid = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
@@ -615,12 +688,18 @@ extern "C" int stil_bn_train_bwd_tiles(const float* dz, const float* z, const fl
                "stil_bn_train_bwd_tiles: workspace too small or not 8-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const int nsplit = bn_bwd_tiles_nsplit(ntiles);
-  hipLaunchKernelGGL(bn_bwd_tiles_stage1_kernel, dim3(cdiv(C, 32), nsplit), dim3(256), 0, s, tilestats, ntiles, C, cdiv(ntiles, nsplit),
-                     (double*)workspace);
-  STIL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_tiles_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)workspace, nsplit, M, C, gamma, stats,
-                     dgamma, dbeta, coef, accumulate);
-  STIL_LAUNCH_CHECK();
+  if (nsplit == 1) {
+    hipLaunchKernelGGL(bn_bwd_tiles_fused_kernel, dim3(cdiv(C, 32)), dim3(256), 0, s, tilestats, ntiles, M, C, gamma, stats, dgamma, dbeta,
+                       coef, accumulate);
+    STIL_LAUNCH_CHECK();
+  } else {
+    hipLaunchKernelGGL(bn_bwd_tiles_stage1_kernel, dim3(cdiv(C, 32), nsplit), dim3(256), 0, s, tilestats, ntiles, C, cdiv(ntiles, nsplit),
+                       (double*)workspace);
+    STIL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_tiles_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const double*)workspace, nsplit, M, C, gamma, stats,
+                       dgamma, dbeta, coef, accumulate);
+    STIL_LAUNCH_CHECK();
+  }
   long total4 = (long)M * C / 4;
   int grid = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
   hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(grid), dim3(256), 0, s, dz, z, x, stats, coef, dx, total4, C, relu);

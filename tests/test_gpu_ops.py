@@ -283,7 +283,8 @@ def test_premasked_residual_gradient_and_deferred_bn_equal_the_plain_blocks(ops,
     print(f"epilogue BN-backward sums vs the reduction pass: worst |d| / max|g| over {nfw - 1} gradients = {worst:.2e}")
 
 
-@pytest.mark.parametrize("M,N,K,mode,resid", [(64 * 5 + 17, 64, 96, 2, False), (1000, 128, 64, 0, True), (130, 256, 512, 2, True), (64, 64, 32, 0, False)])
+@pytest.mark.parametrize("M,N,K,mode,resid", [(64 * 5 + 17, 64, 96, 2, False), (1000, 128, 64, 0, True), (130, 256, 512, 2, True), (64, 64, 32, 0, False),
+                                              (64 * 257 + 3, 64, 64, 2, False)])
 def test_gemm_epilogue_batchnorm_backward_sums(ops, M, N, K, mode, resid):
     """stil_gemm_nt `bstats`: the per-tile sums of g' and g' * xhat the epilogue leaves (g' = the stored gradient, masked by the
     recomputed ReLU sign for mode 2) against float64 sums over the same rows; stil_bn_train_bwd_tiles on them against
@@ -729,7 +730,8 @@ def test_geglu_rowsoftmax_matmul_nn(ops):
     close(od, o); close(sd_.grad, s.grad, name="dlogits"); close(vd.grad, v.grad, name="dv")
 
 
-@pytest.mark.parametrize("M,C,tile_note", [(200, 64, "ragged last tile"), (64 * 37 + 5, 128, "many tiles"), (9000, 256, "two-stage combine"), (40, 64, "single partial tile")])
+@pytest.mark.parametrize("M,C,tile_note", [(200, 64, "ragged last tile"), (64 * 37 + 5, 128, "many tiles"), (9000, 256, "one split, one launch"), (40, 64, "single partial tile"),
+                                           (64 * 300 + 7, 64, "two splits: stage 1 + stage 2 launches")])
 def test_bn_statistics_two_pass_and_tile_paths_agree_with_float64(ops, M, C, tile_note):
     """Training-mode BN statistics three ways: stil_bn_train_fwd (pilot-shifted two-pass), the per-tile Welford partials a
     GEMM epilogue writes (stil_gemm_nt colstats -> stil_bn_train_fwd_tiles), and float64 -- on data whose mean dwarfs its
