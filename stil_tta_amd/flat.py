@@ -87,7 +87,7 @@ class FlatState:
             b.data = b.data.to(device)
 
     # ---- per-step weight re-layouts (layouts.py): one launch for the student (+ heads), one for the teacher
-    def refresh_layouts(self, student: bool = True, teacher: bool = True):
+    def refresh_layouts(self, student: bool = True, teacher: bool = True, side=None):
         """Recompute the GEMM operand layouts of every conv / Linear weight from the CURRENT weights, on the current stream.
         Called by training_step (student at its start, teacher right after the EMA of its parameters); everything that
         changes weights invalidates them again (Adam, EMA, load_state_dict), and stale layouts are never used (ops.cached_layout)."""
@@ -99,6 +99,17 @@ class FlatState:
             for m in self._modules_s:
                 m.register_load_state_dict_post_hook(lambda *_: self.invalidate_layouts(True, False))
             self._module_t.register_load_state_dict_post_hook(lambda *_: self.invalidate_layouts(False, True))
+        if side is not None:
+            # beside the step's stem (im2col, 7x7 conv, max-pool need no layout): the launches go to the side stream, which is
+            # ordered after everything issued so far; consumers on other streams wait for the recorded event at first use
+            main = torch.cuda.current_stream(self.params.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                if student:
+                    self._plans[0].refresh(publish=True)
+                if teacher:
+                    self._plans[1].refresh(publish=True)
+            return
         if student:
             self._plans[0].refresh()
         if teacher:

@@ -120,16 +120,26 @@ class WeightLayouts:
             param._stil_layouts = self
             self.params.append(param)
         self.fresh = False
+        self.event = None             # set by refresh(publish=True)
+        self.waited = set()
 
     def _inside(self, w) -> bool:
         b = self.slab.data_ptr()
         return w.is_cuda and b <= w.data_ptr() and w.data_ptr() + 4 * w.numel() <= b + 4 * self.slab.numel()
 
     @torch.no_grad()
-    def refresh(self):
-        """Recompute every view from the current weights (one launch on the current stream) and mark them usable."""
+    def refresh(self, publish: bool = False):
+        """Recompute every view from the current weights (one launch on the current stream) and mark them usable.
+        publish: the launch runs on a stream other than its consumers' (the side stream, beside the stem of the step): an event
+        is recorded after it, and every other stream waits for that event once, at its first use of a view (ops.cached_layout)."""
         if self.n_blocks:
             lib().weight_layouts(_p(self.slab), _p(self.out), _p(self.jobs), _p(self.blk2job), self.n_blocks, _stream())
+        self.event = None
+        if publish and self.n_blocks:
+            st = torch.cuda.current_stream(self.slab.device)
+            self.event = torch.cuda.Event()
+            self.event.record(st)
+            self.waited = {st.cuda_stream}
         self.fresh = True
 
     def invalidate(self):

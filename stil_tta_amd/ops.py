@@ -142,6 +142,11 @@ def cached_layout(param, attr: str, key=None):
     plan = getattr(param, "_stil_layouts", None)
     if plan is None or not plan.fresh:
         return None
+    if plan.event is not None:      # refreshed on another stream: this stream waits for it once
+        st = torch.cuda.current_stream(plan.slab.device)
+        if st.cuda_stream not in plan.waited:
+            st.wait_event(plan.event)
+            plan.waited.add(st.cuda_stream)
     v = getattr(param, attr, None)
     if v is None or key is None:
         return v

@@ -369,14 +369,17 @@ class STiLModel(_Base):
         # operands, same results as "student, then momentum_update_ema, then teacher" (STiLModel.py:248-257).
         side = ops.side_stream(dev) if self.use_ema else None
         pipe = None
-        self.flat.refresh_layouts(student=True, teacher=False)   # every GEMM operand layout of the student in one launch
         if side is not None:
             with torch.no_grad():
                 self.flat.ema_update_params(hp.ema_momentum)
-            self.flat.refresh_layouts(student=False, teacher=True)   # ... and of the teacher, from its averaged parameters
+            # every GEMM operand layout of the student and of the (just averaged) teacher: two launches on the side stream, beside
+            # the stem of the step
+            self.flat.refresh_layouts(student=True, teacher=True, side=side)
             pipe = TeacherPipe(self.flat, hp.ema_momentum, bool(hp.eman))
             pipe.start.record()
             set_teacher_pipe(pipe)
+        else:
+            self.flat.refresh_layouts(student=True, teacher=False)
         try:
             if pipe is None:
                 s = self.model.forward_all((x_img, x_tab), train=True, mi_masks=masks, cache=cache)
