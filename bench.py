@@ -440,9 +440,9 @@ def main():
         out = dict(metric="training samples/sec (labeled+unlabeled) for DVM STiL", value=round(value, 2), unit="samples/s",
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload=f"config_{'cardiac' if a.variant == 'cardiac' else 'dvm'}_{dict(mmatch='MMatch', comatch='MultiCoMatch', simmatch='MultiSimMatch', freematch='MultiFreeMatch').get(a.variant, 'STiL')}{'_SAINT' if a.variant == 'saint' else ''} ResNet-50 + {'SAINT' if a.variant == 'saint' else 'Transformer'} tabular, batch {a.batch}/GPU "
-                                        f"({a.batch // 8} labelled + {a.batch - a.batch // 8} unlabelled), {a.img}x{a.img} + "
-                                        f"{a.ncat + a.ncon} columns, K={a.classes}, epoch > start_epoch, MI dropout on",
+                   config=dict(workload=f"config_{'cardiac' if a.variant == 'cardiac' else 'dvm'}_{dict(mmatch='MMatch', comatch='MultiCoMatch', simmatch='MultiSimMatch', freematch='MultiFreeMatch').get(a.variant, 'STiL')}{'_SAINT' if a.variant == 'saint' else ''} ResNet-50 + {'SAINT' if a.variant == 'saint' else 'Transformer'} tabular, B={a.batch}/GPU "
+                                        f"({a.batch // 8} l + {a.batch - a.batch // 8} u), {a.img}px + {a.ncat + a.ncon} cols, K={a.classes}, "
+                                        f"pseudo-label phase, MI dropout on",
                                global_batch=a.batch * world, parallelism=f"dp{world}", precision="fp32-exact MFMA",
                                launch="hipGraph replay" if a.graph else "eager",
                                input="host memory through data.DevicePrefetcher (PCIe-inclusive)" if a.host_input else "resident in HBM"),
