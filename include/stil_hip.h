@@ -48,7 +48,14 @@ int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, 
                  const float* bias, const float* sub, const float* scale, const float* shift, const float* resid,
                  int ldr, float* pre, int act, float alpha, float* colstats, const float* a_bn, const float* relu_mask, int ldm,
                  const float* bs_y, const float* bs_stats, float* bstats, int bs_relu, int bs_tile0,
-                 const float* scale_var, float var_eps, int tune, void* stream);
+                 const float* scale_var, float var_eps, void* split_ws, size_t split_ws_bytes, int tune, void* stream);
+/* `split_ws` (optional): split-K for grids below one 64x64 workgroup per CU (small per-GPU batches: the step is then a dependent
+ *   chain of GEMMs that each leave most of the chip idle).  stil_gemm_nt_split_workspace_bytes(M, N, K, tune) > 0 says the product
+ *   would be split; given a workspace of that size (256-byte aligned, ZEROED ONCE before its first use -- it holds one arrival
+ *   ticket per tile, which every launch leaves zero again -- and not shared by launches that may run concurrently: one per stream),
+ *   the tile's slices write their accumulators to slabs and the slice that draws the last ticket adds them in slice order and runs
+ *   the epilogue: deterministic, no workgroup waits.  Without a workspace the product runs unsplit. */
+size_t stil_gemm_nt_split_workspace_bytes(int M, int N, int K, int tune);
 /* `scale_var` (optional, needs `scale`): the per-column scale is scale[n] / sqrtf(scale_var[n] + var_eps) -- an eval-mode BatchNorm
  *   folded into the conv epilogue straight from (weight, bias, running_mean, running_var): sub = running_mean, scale = weight,
  *   scale_var = running_var, shift = bias, formed exactly as stil_bn_eval_affine forms it (models/resnets.py:112-132 in eval mode). */

@@ -68,6 +68,13 @@ struct GemmNTArgs {
   const float* bs_stats;
   float* bstats;
   int ldbs, bs_relu, bs_tile0;
+  // split-K (64x64 tiles; grids below one workgroup per CU): `splits` workgroups share an output tile, each walks its own range
+  // of k-tiles and writes its raw accumulators to a slab; the one that draws the last arrival ticket adds the slabs in split
+  // order (deterministic) and runs the epilogue.  Nobody waits.  tickets: one int per tile, zero before the first launch; the
+  // last arriver leaves it zero.
+  int splits;
+  float* split_slabs;
+  int* split_tickets;
 };
 
 __device__ __forceinline__ float4 ld4_guard(const float* p, int nvalid, int vec) {
@@ -330,7 +337,11 @@ void gemm_nt_kernel(GemmNTArgs p) {
   float* tab = lds + NB * (BM + BN) * LS;   // BNA: [3][C] = mean, a, beta of the producing layer
 
   const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
-  const int wg = xcd_remap(blockIdx.x, nbm * nbn);
+  int wg = xcd_remap(blockIdx.x, nbm * nbn * (TM * TN == 1 ? p.splits : 1));
+  int split = 0;
+  if constexpr (TM * TN == 1) {   // a tile's slices are consecutive: same XCD (speed only)
+    if (p.splits > 1) { split = wg % p.splits; wg /= p.splits; }
+  }
   const int tm = wg / nbn, tn = wg - tm * nbn;
   const int tid = threadIdx.x, kq = tid % KQ, r0 = tid / KQ;
   const ConvGeom g = p.g;
@@ -403,9 +414,21 @@ void gemm_nt_kernel(GemmNTArgs p) {
       a_src[i] = ok ? p.A + ((long)(a_n[i] * g.H + iy) * g.W + ix) * p.lda + kq * 4 : p.A;
     }
   };
-  int cur_tap = 0, c0 = 0, kb = 0;  // c0: channel offset inside the tap; kb = cur_tap*C + c0 (column of W)
+  // this workgroup's range of k-tiles [kt0, kt0 + nk): everything unless the tile is split over K
+  const int per_tap = (g.C + BK - 1) / BK;
+  const int nk_all = (PLAIN ? 1 : g.KH * g.KW) * per_tap;
+  int kt0 = 0, nk = nk_all;
+  if constexpr (TM * TN == 1) {
+    if (p.splits > 1) {
+      int kpt = (nk_all + p.splits - 1) / p.splits;
+      kpt = ((kpt + 64 / BK - 1) / (64 / BK)) * (64 / BK);   // whole partial chains of the two-level accumulation
+      kt0 = min(nk_all, split * kpt);
+      nk = min(nk_all, kt0 + kpt) - kt0;
+    }
+  }
+  int cur_tap = kt0 / per_tap, c0 = (kt0 - cur_tap * per_tap) * BK, kb = cur_tap * g.C + c0;  // c0: channel offset inside the tap; kb = cur_tap*C + c0 (column of W)
   const int ntaps = PLAIN ? 1 : g.KH * g.KW;
-  set_tap(0);
+  set_tap(cur_tap < ntaps ? cur_tap : 0);
   auto gload = [&]() {
     const int nval = g.C - (c0 + kq * 4);   // <= 0 only in the K tail of a plain GEMM (C == K, K % BK != 0)
     if constexpr (BNA) ra_c = c0 + kq * 4;
@@ -459,7 +482,6 @@ void gemm_nt_kernel(GemmNTArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   constexpr int FLUSH = 64 / BK;   // k-tiles per partial chain (ACC2)
 
-  const int nk = ntaps * ((g.C + BK - 1) / BK);
   // Interior fast path (block-uniform): single-tap gathers (plain GEMM, 1x1 conv) whose tile lies fully inside M x N
   // and whose K is a multiple of BK need no predicate at all -> unconditional 16-byte loads, pointer += BK.
   const bool full = VEC && ntaps == 1 && (PLAIN || g.mode == 0) && (g.C % BK == 0) && (tm + 1) * BM <= p.M && (tn + 1) * BN <= p.N;
@@ -511,6 +533,7 @@ void gemm_nt_kernel(GemmNTArgs p) {
         __builtin_amdgcn_s_setprio(0);
       }
     };
+    if (nk <= 0) return;   // an empty slice of a split tile: zero accumulators (block-uniform)
     load();
     lstore(0);
     __syncthreads();
@@ -559,6 +582,44 @@ void gemm_nt_kernel(GemmNTArgs p) {
     }
   };
   if (full) mainloop(std::true_type{}); else mainloop(std::false_type{});
+
+  if constexpr (TM * TN == 1) {
+    if (p.splits > 1) {
+      // The hand-off of cdna_hip_programming.md (split-K, counter form): plain slab stores -> every wave drains its stores ->
+      // workgroup barrier -> ONE lane: agent-scope release, drain, relaxed agent ticket.  The workgroup that draws the last ticket:
+      // ONE lane agent-scope acquire, drain, workgroup barrier, then every wave reads all slabs with plain loads.
+      const long tile = wg;
+      float* slab = p.split_slabs + (tile * p.splits + split) * 4096;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) slab[r * 256 + tid] = acc[0][0][r];     // 256 consecutive floats per register: coalesced
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      int* flag = reinterpret_cast<int*>(lds);    // the operand buffers are free; the ONE LDS array of the kernel
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int old = __hip_atomic_fetch_add(p.split_tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == p.splits - 1;
+        if (last) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(p.split_tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // everybody has arrived: ready for the next launch
+        }
+        flag[0] = last;
+      }
+      __syncthreads();
+      const int last = flag[0];
+      __syncthreads();          // the flag word is operand / epilogue scratch again
+      if (!last) return;        // block-uniform
+      const float* s0 = p.split_slabs + tile * p.splits * 4096;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+      for (int s_ = 0; s_ < p.splits; ++s_) {   // split order: the same sum on every run
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] += s0[(long)s_ * 4096 + r * 256 + tid];
+      }
+    }
+  }
 
   gemm_nt_epilogue<TM, TN, PLAIN>(p, acc, lds, tm, tn, wm, wn, li, lh);
 }
@@ -875,6 +936,28 @@ extern "C" int stil_gemm_nt_config(const float* A, const float* W, int M, int N,
   return variant + 100 * ((vec && bk32) ? (single ? 2 : 1) : 0) + 1000 * (acc2 ? 1 : 0) + 10000 * (vec ? 1 : 0) + 100000 * ((plain && KH * KW == 1) ? 1 : 0);
 }
 
+// split-K policy: only 64x64 tiles whose grid would leave most CUs idle (fewer than one workgroup per CU) and whose reduction is
+// long enough to cut: at least 4 k-tiles (of 32) per slice, at most 16 slices, aiming at >= 512 workgroups.
+static int nt_splits(int M, int N, int K, int tune) {
+  if (stil_gemm_nt_variant(M, N, tune) != 11) return 1;
+  const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
+  if (tiles >= 256 || K < 256) return 1;
+  int s = cdiv(512, tiles);
+  const int maxs = K / 128;
+  if (s > maxs) s = maxs;
+  if (s > 16) s = 16;
+  return s < 2 ? 1 : s;
+}
+// bytes of the split-K workspace stil_gemm_nt wants for this product (0: the product is not split).  Layout: [tiles] int tickets
+// (padded to 256 bytes) then [tiles][splits][64*64] float slabs.  The caller zeroes it ONCE (the tickets); every launch leaves
+// the tickets zero again.  One workspace per stream: launches that may run concurrently must not share one.
+extern "C" size_t stil_gemm_nt_split_workspace_bytes(int M, int N, int K, int tune) {
+  const int s = nt_splits(M, N, K, tune % 10000);
+  if (s <= 1) return 0;
+  const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
+  return (size_t)((tiles * 4 + 255) / 256 * 256) + (size_t)tiles * s * 4096 * sizeof(float);
+}
+
 extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, int lda, int ldb, int ldc,
                             int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad_y,
                             int pad_x, int mode, int out_stride, int out_py, int out_px, int out_OH, int out_OW,
@@ -882,7 +965,7 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
                             const float* shift, const float* resid, int ldr, float* pre, int act, float alpha,
                             float* colstats, const float* a_bn, const float* relu_mask, int ldm,
                             const float* bs_y, const float* bs_stats, float* bstats, int bs_relu, int bs_tile0,
-                            const float* scale_var, float var_eps, int tune_arg, void* stream) {
+                            const float* scale_var, float var_eps, void* split_ws, size_t split_ws_bytes, int tune_arg, void* stream) {
   const int tune = tune_arg % 10000;                 // + 10000: scalar (one dword per lane) epilogue, for A/B measurements and tests
   const bool scalar_epilogue = tune_arg / 10000 == 1;
   STIL_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0, "stil_gemm_nt: null pointer or empty shape (M=%d N=%d K=%d)", M, N, K);
@@ -895,6 +978,16 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   p.g = ConvGeom{srcH, srcW, srcC, OH, OW, KH, KW, stride, pad_y, pad_x, mode};
   p.os = out_stride < 1 ? 1 : out_stride; p.opy = out_py; p.opx = out_px; p.oOH = out_OH; p.oOW = out_OW;
   p.var = scale_var; p.var_eps = var_eps;
+  p.splits = 1; p.split_slabs = nullptr; p.split_tickets = nullptr;
+  {
+    const size_t need = stil_gemm_nt_split_workspace_bytes(M, N, K, tune_arg);
+    if (split_ws && need > 0 && split_ws_bytes >= need && ((uintptr_t)split_ws % 256) == 0) {
+      const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
+      p.splits = nt_splits(M, N, K, tune_arg % 10000);
+      p.split_tickets = (int*)split_ws;
+      p.split_slabs = (float*)((char*)split_ws + (tiles * 4 + 255) / 256 * 256);
+    }
+  }
   STIL_REQUIRE(!scale_var || scale, "stil_gemm_nt: scale_var divides `scale`, which is missing");
   p.bias = bias; p.sub = sub; p.scale = scale; p.shift = shift; p.resid = resid; p.ldr = ldr; p.pre = pre; p.act = act;
   p.alpha = alpha;
@@ -933,7 +1026,7 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
     STIL_REQUIRE(vec && !bk32 && mode == 0 && srcC % 16 == 0 && srcC <= 2048 && (tune % 100 == 0 || tune % 100 == 11),
                  "stil_gemm_nt: a_bn runs 64x64 tiles only (tune %% 100 must be 0 or 11: the caller sizes colstats by "
                  "stil_gemm_nt_tile_rows) and needs 16-byte aligned operands, a forward gather, Cin %% 16 == 0 and Cin <= 2048 (Cin=%d)", srcC);
-    const dim3 grid_(cdiv(M, 64) * cdiv(N, 64));
+    const dim3 grid_(cdiv(M, 64) * cdiv(N, 64) * p.splits);
     const size_t lds_ = (size_t)2 * 64 * 2 * 20 * sizeof(float) + (size_t)3 * srcC * sizeof(float);
     if (acc2 && plain) hipLaunchKernelGGL((gemm_nt_kernel<1, 1, 16, true, true, true, true>), grid_, dim3(256), lds_, s, p);
     else if (acc2) hipLaunchKernelGGL((gemm_nt_kernel<1, 1, 16, true, true, false, true>), grid_, dim3(256), lds_, s, p);
@@ -944,7 +1037,7 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   }
 #define LAUNCH_NT(TM_, TN_, BK_, V_)                                                                          \
   do {                                                                                                        \
-    const dim3 grid_(cdiv(M, 64 * TM_) * cdiv(N, 64 * TN_));                                                  \
+    const dim3 grid_(cdiv(M, 64 * TM_) * cdiv(N, 64 * TN_) * ((TM_) * (TN_) == 1 ? p.splits : 1));              \
     const size_t lds_ = (size_t)2 * 64 * (TM_ + TN_) * (BK_ + 4) * sizeof(float);                             \
     if (acc2 && plain) hipLaunchKernelGGL((gemm_nt_kernel<TM_, TN_, BK_, V_, true, true>), grid_, dim3(256), lds_, s, p);   \
     else if (acc2) hipLaunchKernelGGL((gemm_nt_kernel<TM_, TN_, BK_, V_, true, false>), grid_, dim3(256), lds_, s, p);      \
@@ -954,7 +1047,7 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   if (!vec) {  // unaligned / ragged operands (K = 286 classifier gradients ...): scalar guarded loads
     if (variant == 11) LAUNCH_NT(1, 1, 16, false); else if (variant == 21) LAUNCH_NT(2, 1, 16, false); else if (variant == 12) LAUNCH_NT(1, 2, 16, false); else LAUNCH_NT(2, 2, 16, false);
   } else if (variant == 11 && single) {
-    const dim3 grid_(cdiv(M, 64) * cdiv(N, 64));
+    const dim3 grid_(cdiv(M, 64) * cdiv(N, 64) * p.splits);
     const size_t lds_ = (size_t)64 * 2 * 36 * sizeof(float);
     if (acc2 && plain) hipLaunchKernelGGL((gemm_nt_kernel<1, 1, 32, true, true, true, false, 1>), grid_, dim3(256), lds_, s, p);
     else if (acc2) hipLaunchKernelGGL((gemm_nt_kernel<1, 1, 32, true, true, false, false, 1>), grid_, dim3(256), lds_, s, p);

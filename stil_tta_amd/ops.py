@@ -53,6 +53,26 @@ class _Workspace:
 
 _ws = _Workspace()
 
+
+class _SplitWorkspace:
+    """Split-K workspace of stil_gemm_nt (arrival tickets + slabs), one per (device, stream), ZERO-initialised: the library leaves
+    the tickets zero after every launch, so a buffer is zeroed once, when it is (re)allocated."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        b = self.buf.get(key)
+        if b is None or b.numel() < nbytes:
+            b = torch.zeros(int(nbytes * 1.5) + 4096, dtype=torch.uint8, device=device)
+            self.buf[key] = b
+        return b
+
+
+_split_ws = _SplitWorkspace()
+_SPLITK = __import__("os").environ.get("STIL_SPLITK", "1") != "0"
+
 # per-call tuning arguments of stil_gemm_nt / stil_wgrad_tn (include/stil_hip.h); 0 = automatic.  Only the measurement
 # tools and bench.py's A/B environment knobs (STIL_GEMM_TUNE, STIL_WGRAD_TUNE) set them.
 TUNE = {"gemm": int(__import__("os").environ.get("STIL_GEMM_TUNE", "0")), "wgrad": int(__import__("os").environ.get("STIL_WGRAD_TUNE", "0"))}
@@ -194,12 +214,17 @@ def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None,
                     and geom[0] == geom[3] and geom[1] == geom[4])
         cfg = L.gemm_nt_config(_p(A), _p(W), M, N, K, lda, ldb, geom[2], geom[5], geom[6], plain, int(a_bn is not None), TUNE["gemm"])
         meta = (cfg, 2.0 * M * N * K / s2, (M, N, K, geom[5], geom[7], geom[9]), nbytes)
+    sw, swn = None, 0
+    if _SPLITK:
+        swn = L.gemm_nt_split_workspace_bytes(M, N, K, TUNE["gemm"])
+        if swn:
+            sw = _split_ws.get(swn, A.device)
     L.gemm_nt(_p(A), _p(W), _p(out), M, N, K, lda, ldb, ldc, *geom[:8], pads[0], pads[1], geom[9], *outmap,
               _p(bias), _p(sub), _p(scale), _p(shift), _p(resid),
               (ldc if resid is not None else 0), _p(pre), act, float(alpha), _p(colstats), _p(a_bn), _p(relu_mask),
               (ldc if relu_mask is not None else 0), *((_p(bstats[0]), _p(bstats[1]), _p(bstats[2]), int(bstats[3]), int(bstats[4]))
                                                        if bstats is not None else (None, None, None, 0, 0)),
-              _p(scale_var), float(var_eps), TUNE["gemm"], _stream(), meta=meta)
+              _p(scale_var), float(var_eps), _p(sw), (sw.numel() if sw is not None else 0), TUNE["gemm"], _stream(), meta=meta)
     return out
 
 

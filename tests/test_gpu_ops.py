@@ -860,3 +860,53 @@ def test_weight_layout_plan_equals_the_per_call_layouts_bit_for_bit(ops):
         finally:
             os.environ.pop("STIL_LAYOUT_PLAN")
     assert outs[0][0] == outs[1][0] and all(torch.equal(a, b_) for a, b_ in zip(outs[0][1:], outs[1][1:]))
+
+
+@pytest.mark.parametrize("M,N,K,conv", [(256, 512, 2048, False), (100, 130, 1000, False), (1024, 256, 1024, False), (64, 64, 4608, False), (128, 256, 576, True),
+                                        (256, 286, 1536, False)])
+def test_gemm_split_k_is_the_unsplit_product_and_deterministic(ops, M, N, K, conv):
+    """stil_gemm_nt split-K (grids below one 64x64 workgroup per CU): a tile's slices write their accumulators to slabs, the slice
+    that draws the last arrival ticket adds them in slice order and runs the epilogue.  Against the unsplit launch (same epilogue:
+    bias + residual + ReLU, per-tile statistics) to rounding, bit-identical on repetition with the SAME workspace (the tickets are
+    left zero), and unchanged when two streams run split products at the same time on their own workspaces."""
+    from stil_tta_amd._lib import lib
+    assert lib().gemm_nt_split_workspace_bytes(M, N, K, 0) > 0, "the case is meant to be split"
+    g = torch.Generator().manual_seed(M + K)
+    W, b, R = dev(torch.randn(N, K, generator=g) * 0.05), dev(torch.randn(N, generator=g)), dev(torch.randn(M, N, generator=g))
+    if conv:
+        C = K // 9
+        A, geom = dev(torch.randn(M // 64, 8, 8, C, generator=g)), (8, 8, C, 8, 8, 3, 3, 1, 1, 0)
+    else:
+        A, geom = dev(torch.randn(M, K, generator=g)), None
+    nt = (M + 63) // 64
+
+    def run(split):
+        ops._SPLITK = split
+        try:
+            ts = torch.zeros(2 * nt, N, device="cuda")
+            raw = ops.gemm_nt(A, W, M, N, K, geom=geom, colstats=ts if N % 4 == 0 else None)
+            out = ops.gemm_nt(A, W, M, N, K, geom=geom, bias=b, resid=R, act=1)
+            torch.cuda.synchronize()
+            return raw, out, ts
+        finally:
+            ops._SPLITK = True
+    ref = run(False)
+    got = [run(True) for _ in range(3)]
+    for u, v, nm in zip(got[0], ref, ("raw", "epilogue", "tile statistics")):
+        close(u, v, tol=1e-5, name=f"split-K {nm} vs unsplit")
+    for rep in got[1:]:
+        assert all(torch.equal(u, v) for u, v in zip(rep, got[0])), "split-K is not bit-identical on repetition"
+    if not conv:   # and against ATen
+        close(got[0][1], F.relu(A.cpu() @ W.cpu().t() + b.cpu() + R.cpu()), name="split-K vs ATen")
+    # two streams, each with its own workspace, at the same time
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    A2 = A * 0.5
+    outs = {}
+    torch.cuda.synchronize()
+    for it in range(8):
+        for st, a_, key in ((s1, A, "a"), (s2, A2, "b")):
+            with torch.cuda.stream(st):
+                outs[key] = ops.gemm_nt(a_, W, M, N, K, geom=geom, bias=b, resid=R, act=1)
+    torch.cuda.synchronize()
+    assert torch.equal(outs["a"], got[0][1]), "split-K result changed when another stream ran a split product beside it"
+    close(outs["b"], ops.gemm_nt(A2, W, M, N, K, geom=geom, bias=b, resid=R, act=1), tol=0.0, name="second stream")

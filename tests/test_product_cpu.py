@@ -33,7 +33,7 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     from stil_tta_amd._lib import lib
     L = lib()
     with pytest.raises(RuntimeError, match="null pointer"):
-        L.gemm_nt(None, None, None, 4, 4, 4, 4, 4, 4, 1, 1, 4, 1, 1, 1, 1, 1, 0, 0, 0, 1, 0, 0, 1, 1, None, None, None, None, None, 0, None, 0, 1.0, None, None, None, 0, None, None, None, 0, 0, None, 0.0, 0, None)
+        L.gemm_nt(None, None, None, 4, 4, 4, 4, 4, 4, 1, 1, 4, 1, 1, 1, 1, 1, 0, 0, 0, 1, 0, 0, 1, 1, None, None, None, None, None, 0, None, 0, 1.0, None, None, None, 0, None, None, None, 0, 0, None, 0.0, None, 0, 0, None)
     with pytest.raises(RuntimeError, match="multiple of 4"):
         L.ema_update(ctypes.c_void_p(16), ctypes.c_void_p(32), 6, 0.9, None)
     assert L.wgrad_workspace_bytes(1 << 20, 64, 576, 0) > 0
