@@ -51,8 +51,9 @@ int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, 
                  const float* scale_var, float var_eps, void* split_ws, size_t split_ws_bytes, int tune, void* stream);
 /* `split_ws` (optional): split-K for grids below one 64x64 workgroup per CU (small per-GPU batches: the step is then a dependent
  *   chain of GEMMs that each leave most of the chip idle).  stil_gemm_nt_split_workspace_bytes(M, N, K, tune) > 0 says the product
- *   would be split; given a workspace of that size (256-byte aligned, ZEROED ONCE before its first use -- it holds one arrival
- *   ticket per tile, which every launch leaves zero again -- and not shared by launches that may run concurrently: one per stream),
+ *   would be split; given a workspace of at least that size (256-byte aligned, ZEROED ONCE before its first use -- its first 4 KB
+ *   hold one arrival ticket per tile, which every launch leaves zero again; products of different shapes may share it -- and not
+ *   shared by launches that may run concurrently: one per stream),
  *   the tile's slices write their accumulators to slabs and the slice that draws the last ticket adds them in slice order and runs
  *   the epilogue: deterministic, no workgroup waits.  Without a workspace the product runs unsplit. */
 size_t stil_gemm_nt_split_workspace_bytes(int M, int N, int K, int tune);

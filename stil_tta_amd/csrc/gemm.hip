@@ -948,14 +948,17 @@ static int nt_splits(int M, int N, int K, int tune) {
   if (s > 16) s = 16;
   return s < 2 ? 1 : s;
 }
-// bytes of the split-K workspace stil_gemm_nt wants for this product (0: the product is not split).  Layout: [tiles] int tickets
-// (padded to 256 bytes) then [tiles][splits][64*64] float slabs.  The caller zeroes it ONCE (the tickets); every launch leaves
-// the tickets zero again.  One workspace per stream: launches that may run concurrently must not share one.
+// bytes of the split-K workspace stil_gemm_nt wants for this product (0: the product is not split).  Layout: a FIXED ticket
+// region of NT_SPLIT_TICKET_BYTES (one int per tile; split products have fewer than 256 tiles) then [tiles][splits][64*64] float
+// slabs -- fixed, so that one workspace can serve products of different shapes: no product's slabs ever overlap another's tickets.
+// The caller zeroes it ONCE (the tickets); every launch leaves the tickets zero again.  One workspace per stream: launches that
+// may run concurrently must not share one.
+#define NT_SPLIT_TICKET_BYTES 4096
 extern "C" size_t stil_gemm_nt_split_workspace_bytes(int M, int N, int K, int tune) {
   const int s = nt_splits(M, N, K, tune % 10000);
   if (s <= 1) return 0;
   const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
-  return (size_t)((tiles * 4 + 255) / 256 * 256) + (size_t)tiles * s * 4096 * sizeof(float);
+  return (size_t)NT_SPLIT_TICKET_BYTES + (size_t)tiles * s * 4096 * sizeof(float);
 }
 
 extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, int lda, int ldb, int ldc,
@@ -985,7 +988,8 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
       const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
       p.splits = nt_splits(M, N, K, tune_arg % 10000);
       p.split_tickets = (int*)split_ws;
-      p.split_slabs = (float*)((char*)split_ws + (tiles * 4 + 255) / 256 * 256);
+      p.split_slabs = (float*)((char*)split_ws + NT_SPLIT_TICKET_BYTES);
+      (void)tiles;
     }
   }
   STIL_REQUIRE(!scale_var || scale, "stil_gemm_nt: scale_var divides `scale`, which is missing");

@@ -898,6 +898,12 @@ def test_gemm_split_k_is_the_unsplit_product_and_deterministic(ops, M, N, K, con
         assert all(torch.equal(u, v) for u, v in zip(rep, got[0])), "split-K is not bit-identical on repetition"
     if not conv:   # and against ATen
         close(got[0][1], F.relu(A.cpu() @ W.cpu().t() + b.cpu() + R.cpu()), name="split-K vs ATen")
+    # the workspace is shared by products of other shapes (more tiles, fewer tiles) on the same stream: their slabs must never
+    # land where this product keeps its arrival tickets
+    for (m2, n2, k2) in ((832, 256, 512), (64, 128, 1024)):
+        ops.gemm_nt(torch.randn(m2, k2, device="cuda"), torch.randn(n2, k2, device="cuda"), m2, n2, k2)
+        again = ops.gemm_nt(A, W, M, N, K, geom=geom, bias=b, resid=R, act=1)
+        assert torch.equal(again, got[0][1]), f"split-K result changed after a ({m2}, {n2}, {k2}) product used the same workspace"
     # two streams, each with its own workspace, at the same time
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     A2 = A * 0.5
