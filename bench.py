@@ -444,7 +444,7 @@ def main():
                                         f"({a.batch // 8} l + {a.batch - a.batch // 8} u), {a.img}px + {a.ncat + a.ncon} cols, K={a.classes}, "
                                         f"pseudo-label phase, MI dropout on",
                                global_batch=a.batch * world, parallelism=f"dp{world}", precision="fp32-exact MFMA",
-                               launch="hipGraph replay" if a.graph else "eager",
+                               launch="hipGraph replay" if a.graph else "eager", split_k=bool(__import__("stil_tta_amd.ops", fromlist=["_SPLITK"])._SPLITK),
                                input="host memory through data.DevicePrefetcher (PCIe-inclusive)" if a.host_input else "resident in HBM"),
                    ms_per_step_by_rank=[round(x / a.steps * 1e3, 3) for x in per_rank],
                    roofline=roof, loss=round(loss, 5),

@@ -611,13 +611,18 @@ void gemm_nt_kernel(GemmNTArgs p) {
       const int last = flag[0];
       __syncthreads();          // the flag word is operand / epilogue scratch again
       if (!last) return;        // block-uniform
+      // slice order, in DOUBLE, rounded to fp32 once: the same sum on every run, and each slice's partial enters exactly (the
+      // split product carries less rounding noise than the unsplit chain of K / 64 partial sums it replaces)
       const float* s0 = p.split_slabs + tile * p.splits * 4096;
+      double dsum[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
-      for (int s_ = 0; s_ < p.splits; ++s_) {   // split order: the same sum on every run
+      for (int r = 0; r < 16; ++r) dsum[r] = 0.0;
+      for (int s_ = 0; s_ < p.splits; ++s_) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][0][r] += s0[(long)s_ * 4096 + r * 256 + tid];
+        for (int r = 0; r < 16; ++r) dsum[r] += (double)s0[(long)s_ * 4096 + r * 256 + tid];
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][0][r] = (float)dsum[r];
     }
   }
 

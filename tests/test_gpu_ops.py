@@ -889,9 +889,10 @@ def test_gemm_split_k_is_the_unsplit_product_and_deterministic(ops, M, N, K, con
             torch.cuda.synchronize()
             return raw, out, ts
         finally:
-            ops._SPLITK = True
+            ops._SPLITK = False
     ref = run(False)
     got = [run(True) for _ in range(3)]
+    ops._SPLITK = True       # (restored at the end of the test)
     for u, v, nm in zip(got[0], ref, ("raw", "epilogue", "tile statistics")):
         close(u, v, tol=1e-5, name=f"split-K {nm} vs unsplit")
     for rep in got[1:]:
@@ -914,5 +915,8 @@ def test_gemm_split_k_is_the_unsplit_product_and_deterministic(ops, M, N, K, con
             with torch.cuda.stream(st):
                 outs[key] = ops.gemm_nt(a_, W, M, N, K, geom=geom, bias=b, resid=R, act=1)
     torch.cuda.synchronize()
-    assert torch.equal(outs["a"], got[0][1]), "split-K result changed when another stream ran a split product beside it"
-    close(outs["b"], ops.gemm_nt(A2, W, M, N, K, geom=geom, bias=b, resid=R, act=1), tol=0.0, name="second stream")
+    try:
+        assert torch.equal(outs["a"], got[0][1]), "split-K result changed when another stream ran a split product beside it"
+        close(outs["b"], ops.gemm_nt(A2, W, M, N, K, geom=geom, bias=b, resid=R, act=1), tol=0.0, name="second stream")
+    finally:
+        ops._SPLITK = False

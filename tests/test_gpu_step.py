@@ -219,6 +219,41 @@ def test_training_step_matches_reference_golden(name):
         assert ok, (key, err)
 
 
+@pytest.mark.parametrize("name", ["dvm_r50_pseudo", "cardiac_r50", "dvm_saint"])
+def test_training_step_with_split_k_matches_reference_golden(name):
+    """The opt-in split-K form of the small NT products (ops._SPLITK; what a per-GPU batch of 16-64 samples wants) in the whole
+    step: the forward quantities of three reference goldens at the north-star 1e-4 and exact CGPL decisions, bit-identical on
+    repetition (arrival tickets, slice-order sums: deterministic)."""
+    from stil_tta_amd import ops
+    from stil_tta_amd.driver import train_step
+    from stil_tta_amd.flat import StilAdam
+    fx = np.load(os.path.join(GOLD, name + ".npz"))
+    outs = []
+    ops._SPLITK = True
+    try:
+        for rep in range(2):
+            hp, sd, batch, epoch, mask_random, mi_masks = build_case(name)
+            m = _make_model(hp, sd)
+            m.current_epoch = epoch
+            opt = StilAdam(m.flat, lr=hp.lr_eval, weight_decay=hp.weight_decay_eval)
+            train_step(m, opt, _to_dev(batch), mask_random=mask_random, mi_masks=mi_masks)
+            torch.cuda.synchronize()
+            outs.append((m.flat.params.clone(), m.flat.grads.clone(), {k: m.last[k].detach().clone() for k in SCALARS + FWD_KEYS}, m.last["flags"].cpu().numpy()))
+    finally:
+        ops._SPLITK = False
+    last, f = outs[0][2], outs[0][3]
+    bad = []
+    for k in SCALARS + FWD_KEYS:
+        d = _scaled(last[k].cpu().numpy(), fx["out_" + k])
+        if d > NORTH_STAR:
+            bad.append((k, d))
+    for cid, key in ((1, "case1"), (2, "case2_i"), (3, "case2_t"), (4, "case3")):
+        assert np.array_equal(f[:, 0] == cid, fx["out_" + key]), key
+    assert np.array_equal(f[:, 1].astype(bool), fx["out_mask1"])
+    assert not bad, bad
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "split-K step is not bit-identical on repetition"
+
+
 def test_two_steps_match_oracle_dvm_native_shape():
     """DVM-native config (128 px, 4 cat + 13 con, K = 286), B = 16, two consecutive steps incl. Adam + EMA +
     BN running stats + prototype commit, against the CPU oracle on identical seeded inputs."""
