@@ -10,7 +10,7 @@ void stil_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* stil_last_error(void) { return g_err; }
-extern "C" int stil_version(void) { return 100; }
+extern "C" int stil_version(void) { return 104; }   // round 4: stil_gemm_nt gained bstats / scale_var / split_ws, stil_weight_layouts, stil_bn_train_bwd_tiles
 // number of HIP devices visible (0 = none): lets the host fail loudly before any launch
 extern "C" int stil_device_count(void) {
   int n = 0;
