@@ -249,3 +249,31 @@ def test_bench_gpus_2_runs_two_ranks_end_to_end():
     # two ranks share the box's one GPU: HIP-event durations price nothing there, and the line says so instead of printing a number
     assert j["roofline"] is None and "share a device" in j["roofline_reason"], ctx
     assert "cpu_baseline" not in j and j["loss"] == j["loss"], ctx
+
+
+def test_bench_line_single_gpu_carries_the_contract_fields():
+    """`python bench.py` as the driver calls it at N = 1 (tiny shapes here): ONE JSON line with the contract's keys, a `roofline`
+    object for the dominant gemm_nt instantiation measured with HIP events (structure and sanity ranges only: nothing that depends
+    on how fast the box is) and a `cpu_baseline` object timed on the job's CPU share."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "STIL_DIST_BACKEND")}
+    cmd = [sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--batch", "16", "--img", "64", "--ncat", "3", "--ncon", "5", "--classes", "7",
+           "--cpu-steps", "1"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=420)
+    ctx = f"\nstdout: {r.stdout[-3000:]}\nstderr tail: {r.stderr[-3000:]}"
+    assert r.returncode == 0, ctx
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, ctx
+    j = lines[0]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in j, (k, ctx)
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["unit"] == "samples/s" and j["dtype"] == "f32" and j["vs_baseline"] is None and j["scaling"] == "weak", ctx
+    assert j["config"]["global_batch"] == 16 and j["config"]["parallelism"] == "dp1" and "workload" in j["config"] and "model" not in j["config"], ctx
+    rf = j["roofline"]
+    assert rf is not None and rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3 and rf["kernel"].startswith("gemm_nt_kernel<"), ctx
+    assert 0.0 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["launches_per_step"] > 0 and rf["flops_per_step"] > 0, ctx
+    cb = j["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "samples/s" and cb["value"] > 0 and 1 <= cb["cores"] <= (os.cpu_count() or 1), ctx
+    assert j["value"] > 0 and abs(j["value"] * j["ms_per_step"] - 16 * 1e3) < 1e-2 * 16 * 1e3 and len(j["ms_per_step_by_rank"]) == 1, ctx
