@@ -14,7 +14,7 @@ For every case it
   3. asserts oracle == reference to 2e-5 (abs+rel),
   4. stores the REFERENCE's outputs as the golden vectors (tensors only).
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py [case ...]      (default: every case + the Adam layout)
 """
 from __future__ import annotations
 
@@ -230,6 +230,10 @@ CASES = {
     "dvm_r18_noeman": (dict(model="resnet18", embedding_dim=512, img_size=64, num_classes=5,
                             field_lengths=[3, 4] + [1] * 3, batch_size=8, th1=0.25, start_epoch=1, eman=False),
                        8, 3, False, True),
+    # BASELINE.json configs[0] at its real shape: ResNet-50, 224 px, 16 categorical (cardinality 8) + 48 continuous columns,
+    # K = 286, batch 32 (4 labelled + 28 unlabelled), pseudo-label phase, MI-layer dropout masks injected (see build_case)
+    "dvm_r50_b32_224": (dict(img_size=224, num_classes=286, field_lengths=[8] * 16 + [1] * 48, batch_size=32, th1=0.5, start_epoch=0),
+                        32, 1, True, True),
 }
 
 VAL_KEYS = ["val_loss", "val_loss_ce", "val_loss_itc", "test_probs"]
@@ -270,7 +274,25 @@ def build_case(name):
             nf = Nt + 1
             mi_masks["saint"] = {"ff_col": torch.rand(B, nf, 4 * O.SAINT_DIM, generator=g2) >= hp.saint_ff_drop,
                                  "ff_row": torch.rand(1, B, 4 * O.SAINT_DIM * nf, generator=g2) >= hp.saint_ff_drop}
-    if prefill:
+    if prefill and name == "dvm_r50_b32_224":
+        # couple the three classifiers (imaging / tabular heads reuse the e_si / e_st slices of the multimodal head, whose e_st
+        # slice is boosted: token means over 64 columns vary little between samples) so that the CGPL cases are mixed, and put
+        # th1 into the widest gap of the confidence ranking (prediction does not depend on th1): a mixed mask1 that no rounding
+        # difference between two evaluations can flip
+        for pre_ in ("model.", "ema."):
+            sd[pre_ + "classifier_multimodal.weight"][:, 512:1024] *= 0.3
+            sd[pre_ + "classifier_multimodal.weight"][:, 1024:] *= 28.0
+        sd = craft_heads(sd, batch, hp, epoch, mask_random, scale=6.0, fi=1.0, ft=1.0)
+        with torch.no_grad():
+            pre = O.training_step({k: v.clone() for k, v in sd.items()}, batch, hp, epoch, mask_random, None)
+        B_u = B - max(B // 8, 1)
+        conf = pre["prediction"].max(1)[0].sort()[0]
+        lo = B_u // 4
+        gaps = conf[lo + 1: B_u - lo + 1] - conf[lo: B_u - lo]
+        j = int(gaps.argmax()) + lo
+        hp.th1 = float((conf[j] + conf[j + 1]) / 2)
+        assert float(gaps.max()) > 1e-4
+    elif prefill:
         sd = craft_heads(sd, batch, hp, epoch, mask_random)
     return hp, sd, batch, epoch, mask_random, mi_masks
 
@@ -437,7 +459,8 @@ def main():
     install_stubs()
     torch.manual_seed(0)
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
-    for name in CASES:
+    only = [a for a in sys.argv[1:] if a in CASES]          # `python oracle/make_golden.py [case ...]`: default every case
+    for name in (only or CASES):
         hp, sd, batch, epoch, mask_random, mi_masks = build_case(name)
         ref_out, ref_grads, ref_state = run_reference(hp, {k: v.clone() for k, v in sd.items()}, batch, epoch, mask_random, mi_masks)
         sd_o = {k: v.clone() for k, v in sd.items()}
