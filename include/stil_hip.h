@@ -120,11 +120,14 @@ int stil_conv_weight_layout_phase(const float* w, float* w_sub, int Cout, int Ci
  * transpose, kind 2 = dgrad phase).  jobs: device array of n records of stil_weight_layout_job_bytes() bytes
  *   { int64 src, dst (float offsets into src_base / dst_base); int32 kind, Cout, Cin, KH, KW, stride, ky0, kx0, KHs, KWs,
  *     first_block, pad }
- * blk2job[b] = job of grid block b (1024 destination elements per block; block b is the (b - first_block)-th of its job).
+ * blk2job[b] = job of grid block b (block b is the (b - first_block)-th of its job; a job has
+ * stil_weight_layout_job_blocks(kind, ...) blocks: 32x32 transpose tiles for kind 1, (output channel, 128-channel chunk) pairs
+ * for kind 0 (KH*KW <= 9), 1024 destination elements for kind 2).
  * Replaces the per-layer calls of stil_conv_weight_layout / _phase / stil_transpose on the step path
  * (models/resnets.py:112-132 nn.Conv2d weights; nn.Linear weights of models/Transformer.py, disentangle_transformer.py). */
 int stil_weight_layouts(const float* src_base, float* dst_base, const void* jobs, const int* blk2job, int n_blocks, void* stream);
 int stil_weight_layout_job_bytes(void);
+int stil_weight_layout_job_blocks(int kind, int Cout, int Cin, int KH, int KW, int KHs, int KWs);
 int stil_im2col_nchw(const float* x, float* col, int N, int Cin, int H, int W, int OH, int OW, int KH,
                      int KW, int stride, int pad, int Kp, void* stream);
 int stil_transpose(const float* in, float* out, int R, int C, void* stream);

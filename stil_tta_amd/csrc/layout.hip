@@ -5,8 +5,7 @@
 //   kind 2  [Cin][ky'][kx'][Cout]       one output phase of a strided input-gradient (conv_w_phase_kernel's map)
 // of every layer, once per optimisation step (weights change only in Adam / the EMA update).  Round 3 issued one small
 // kernel per layer and use: 136 launches per step (76 transposes, 45 layouts, 15 phases) of 4-6 us each.  Here a job table
-// (built once per model on the host) drives one grid: block b copies 1024 destination elements of job blk2job[b]
-// (destination-linear: coalesced stores, gathered loads from a tensor that is L2-resident for its whole job).
+// (built once per model on the host) drives one grid; block b works on job blk2job[b] (its (b - first_block)-th block).
 #include "common.h"
 
 struct LayoutJob {
@@ -16,40 +15,66 @@ struct LayoutJob {
   int first_block, pad_;       // first grid block of this job
 };
 
+// Blocks per job (the host builds blk2job with the same rule, stil_weight_layout_job_blocks):
+//   kind 1: one 32x32 tile of the [Cout] x [Cin*taps] -> [Cin*taps] x [Cout] transpose per block (through LDS: both sides coalesced);
+//   kind 0: one (output channel, 128-input-channel chunk) per block: its 128*taps source floats are contiguous, staged in LDS and
+//           written back as `taps` runs of 128 contiguous floats;
+//   kind 2: 1024 destination elements per block (a gather over the few strided convolutions: 4 of 53 layers).
 __global__ __launch_bounds__(256) void weight_layouts_kernel(const float* __restrict__ src_base, float* __restrict__ dst_base,
                                                               const LayoutJob* __restrict__ jobs, const int* __restrict__ blk2job) {
+  __shared__ float buf[1152];      // kind 0: 128 x 9; kind 1: 32 x 33
   const LayoutJob j = jobs[blk2job[blockIdx.x]];
   const float* __restrict__ w = src_base + j.src;
   float* __restrict__ out = dst_base + j.dst;
   const int taps = j.KH * j.KW;
-  const long total = j.kind == 2 ? (long)j.Cin * j.KHs * j.KWs * j.Cout : (long)j.Cout * j.Cin * taps;
-  const long i0 = ((long)blockIdx.x - j.first_block) * 1024 + threadIdx.x;
+  const int lb = blockIdx.x - j.first_block, tid = threadIdx.x;
+  if (j.kind == 1) {               // out[c * R + r] = w[r * C + c],  R = Cout, C = Cin * taps
+    const int R = j.Cout, C = j.Cin * taps, tiles_c = (C + 31) / 32;
+    const int tr = lb / tiles_c, tc = lb - tr * tiles_c, tx = tid & 31, ty = tid >> 5;
+    for (int k = ty; k < 32; k += 8) {
+      const int r = tr * 32 + k, c = tc * 32 + tx;
+      buf[k * 33 + tx] = (r < R && c < C) ? w[(long)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+      const int c = tc * 32 + k, r = tr * 32 + tx;
+      if (r < R && c < C) out[(long)c * R + r] = buf[tx * 33 + k];
+    }
+  } else if (j.kind == 0) {        // out[(co*taps + tap)*Cin + ci] = w[(co*Cin + ci)*taps + tap]
+    const int chunks = (j.Cin + 127) / 128;
+    const int co = lb / chunks, ci0 = (lb - co * chunks) * 128, n = min(128, j.Cin - ci0);
+    const float* s = w + ((long)co * j.Cin + ci0) * taps;
+    for (int e = tid; e < n * taps; e += 256) buf[e] = s[e];
+    __syncthreads();
+    for (int e = tid; e < n * taps; e += 256) {
+      const int tap = e / n, c = e - tap * n;
+      out[((long)co * taps + tap) * j.Cin + ci0 + c] = buf[c * taps + tap];
+    }
+  } else {                         // out[((ci*KHs + ky)*KWs + kx)*Cout + co] = w[co][ci][ky0 + s*(KHs-1-ky)][kx0 + s*(KWs-1-kx)]
+    const long total = (long)j.Cin * j.KHs * j.KWs * j.Cout;
+    const long i0 = (long)lb * 1024 + tid;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const long i = i0 + u * 256;
-    if (i >= total) break;
-    long s;
-    if (j.kind == 0) {          // out[(co*taps + tap)*Cin + ci]
-      const int ci = (int)(i % j.Cin);
-      const long t = i / j.Cin;
-      const int tap = (int)(t % taps), co = (int)(t / taps);
-      s = ((long)co * j.Cin + ci) * taps + tap;
-    } else if (j.kind == 1) {   // out[(ci*taps + tap)*Cout + co]
-      const int co = (int)(i % j.Cout);
-      const long t = i / j.Cout;
-      const int tap = (int)(t % taps), ci = (int)(t / taps);
-      s = ((long)co * j.Cin + ci) * taps + tap;
-    } else {                    // out[((ci*KHs + ky)*KWs + kx)*Cout + co] = w[co][ci][ky0 + s*(KHs-1-ky)][kx0 + s*(KWs-1-kx)]
+    for (int u = 0; u < 4; ++u) {
+      const long i = i0 + u * 256;
+      if (i >= total) break;
       const int co = (int)(i % j.Cout);
       long t = i / j.Cout;
       const int kx = (int)(t % j.KWs); t /= j.KWs;
       const int ky = (int)(t % j.KHs);
       const int ci = (int)(t / j.KHs);
       const int sy = j.ky0 + j.stride * (j.KHs - 1 - ky), sx = j.kx0 + j.stride * (j.KWs - 1 - kx);
-      s = (((long)co * j.Cin + ci) * j.KH + sy) * j.KW + sx;
+      out[i] = w[(((long)co * j.Cin + ci) * j.KH + sy) * j.KW + sx];
     }
-    out[i] = w[s];
   }
+}
+
+// blocks of one job (the rule above), for the host's blk2job table
+extern "C" int stil_weight_layout_job_blocks(int kind, int Cout, int Cin, int KH, int KW, int KHs, int KWs) {
+  const int taps = KH * KW;
+  if (taps > 9 && kind == 0) return -1;     // the LDS stage of kind 0 holds 128 x 9 floats
+  if (kind == 1) return cdiv(Cout, 32) * cdiv((long)Cin * taps, 32);
+  if (kind == 0) return Cout * cdiv(Cin, 128);
+  return cdiv((long)Cin * KHs * KWs * Cout, 1024);
 }
 
 extern "C" int stil_weight_layouts(const float* src_base, float* dst_base, const void* jobs, const int* blk2job, int n_blocks,

@@ -76,7 +76,7 @@ class WeightLayouts:
                     seen.add(id(w))
                     Cout, Cin, KH, KW = w.shape
                     k, stride, pad = m.kernel_size[0], m.stride[0], m.padding[0]
-                    if Cin % 4 != 0:       # the stem (3 input channels) goes through its own im2col + padded weight
+                    if Cin % 4 != 0 or KH * KW > 9:   # the stem (3 input channels, 7x7) goes through its own im2col + padded weight
                         continue
                     if KH * KW > 1:
                         add(w, "_stil_wf", None, 0, Cout, Cin, KH, KW, (Cout, KH * KW * Cin))
@@ -98,7 +98,8 @@ class WeightLayouts:
         recs, blk2job, nb = [], [], 0
         for j, (src, dst, kind, Cout, Cin, KH, KW, stride, ky0, kx0, KHs, KWs, n) in enumerate(jobs):
             recs.append(_JOB.pack(src, dst, kind, Cout, Cin, KH, KW, stride, ky0, kx0, KHs, KWs, nb, 0))
-            b = (n + 1023) // 1024
+            b = lib().weight_layout_job_blocks(kind, Cout, Cin, KH, KW, KHs, KWs)
+            assert b > 0, "unsupported layout job"
             blk2job += [j] * b
             nb += b
         self.n_blocks = nb
