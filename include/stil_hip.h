@@ -80,8 +80,8 @@ int stil_gemm_nt_bstats_ok(const float* C, int N, int ldc, const float* resid, i
  *   64x64 tiles with 16-deep k-tiles: `tune` must leave the tile automatic or ask for 11 (colstats is sized by tile rows).
  * `tune` (0 = automatic; otherwise for A/B measurements) = variant + 100 * bk32 + 1000 * acc2:
  *   variant  block tile: 22 = 128x128, 21 = 128x64, 12 = 64x128, 11 = 64x64 (0: automatic = 64x64, the fastest on the shapes of the step);
- *   bk32     32-deep LDS k-tiles instead of 16: 0 = automatic (plain products: two LDS buffers for K >= 256, one below),
- *            1 = wherever possible (two LDS buffers), 2 = never, 3 = wherever possible in ONE LDS buffer (64x64 tiles);
+ *   bk32     32-deep LDS k-tiles instead of 16: 0 = automatic (= 3 wherever the reduction allows: K % 32 == 0 and 1x1 or Cin % 32 == 0;
+ *            never with a_bn), 1 = wherever possible in two LDS buffers, 2 = never, 3 = wherever possible in ONE LDS buffer (64x64 tiles);
  *   acc2     two-level accumulation (partial chains of 64 products added to a master accumulator, ~ATen-CPU's
  *            rounding noise for long reductions): 0 = for K >= 512, 1 = never, 2 = always.
  *   + 10000  scalar epilogue (one dword per lane) instead of the 16-byte one 64x64 tiles use when N, ldc, ldr % 4 == 0 and

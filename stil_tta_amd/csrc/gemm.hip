@@ -926,14 +926,15 @@ extern "C" int stil_gemm_nt_config(const float* A, const float* W, int M, int N,
                                    int plain, int a_bn, int tune) {
   tune %= 10000;
   const int variant = stil_gemm_nt_variant(M, N, tune);
-  // 32-deep k-tiles: every staged row is one whole 128-byte line (16-deep tiles take half a line per k-tile and count on
-  // L1 for the other half); with the 16-byte epilogue they win on the plain products with K >= 256 (+3..10 %,
-  // profiles/r03_experiments.txt) although only 4 workgroups fit a CU, and lose on the conv gathers and the short ones.
-  const int bkd = (tune / 100) % 10;   // 0 automatic, 1 on (two LDS buffers), 2 off, 3 on with ONE LDS buffer
-  const bool bk32 = (bkd == 1 || bkd == 3 || (bkd == 0 && plain && KH * KW == 1 && !a_bn)) && (K % 32 == 0) && (KH * KW == 1 || srcC % 32 == 0);
-  // ... in ONE LDS buffer for the short plain products (K < 256: +3..7 %, as many workgroups per CU as 16-deep tiles), in
-  // two for the long ones (+3..10 %)
-  const bool single = bk32 && (bkd == 3 || (bkd == 0 && K < 256));
+  // 32-deep k-tiles: every staged row is one whole 128-byte line (16-deep tiles take half a line per k-tile and count on L1 for
+  // the other half), in ONE LDS buffer (two barriers per k-tile, the LDS of a 16-deep pair: as many workgroups per CU), wherever the
+  // reduction allows it: K % 32 == 0 and whole taps (1x1, or Cin % 32 == 0); the operand-staging BatchNorm keeps 16-deep tiles.
+  // Round 3 used them for plain products only (two buffers from K = 256 on); round 4 measured the whole step, paired runs on one
+  // box: everything single-buffered 32-deep +1.0 % (8 of 8 pairs), plain K >= 256 alone -0.5 %, conv gathers alone +-0 --
+  // the mix of LDS footprints of the two streams' kernels matters, not one kernel's own rate (profiles/r04_experiments.txt 12).
+  const int bkd = (tune / 100) % 10;   // 0 automatic (= 3 where possible), 1 on (two LDS buffers), 2 off, 3 on with ONE LDS buffer
+  const bool bk32 = (bkd == 1 || bkd == 3 || (bkd == 0 && !a_bn)) && (K % 32 == 0) && (KH * KW == 1 || srcC % 32 == 0);
+  const bool single = bk32 && (bkd == 3 || bkd == 0);
   const bool acc2 = tune / 1000 == 2 || (tune / 1000 == 0 && K >= 512);
   const bool vec = is_vec(A, lda) && (srcC % 4 == 0) && is_vec(W, ldb) && (K % 4 == 0);  // every 16-byte load aligned and entirely in or out
   if (a_bn)   // operand-staging BatchNorm: 64x64 tiles, BK = 16 (see stil_gemm_nt)
