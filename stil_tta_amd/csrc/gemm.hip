@@ -326,7 +326,7 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNTArgs& p, f32x16 (&a
 // 1 = one buffer, two barriers per k-tile, half the LDS: a 32-deep tile then costs what two 16-deep buffers cost and as
 // many workgroups fit a CU (the barriers are free: other workgroups' MFMAs fill them).
 template <int TM, int TN, int BK, bool VEC, bool ACC2 = false, bool PLAIN = false, bool BNA = false, int NB = 2>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(((BK == 16 || NB == 1) && VEC) ? (TM * TN == 1 ? ((NB == 1 && ACC2) ? 4 : ((BNA && !PLAIN && (ACC2 || BK == 32)) ? 5 : 6)) : ((TM * TN == 2 && ACC2 && (PLAIN || TN == 2)) ? 4 : 1)) : 1)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(((BK == 16 || NB == 1) && VEC) ? (TM * TN == 1 ? ((NB == 1 && ACC2) ? 4 : ((BNA && ACC2 && !PLAIN) ? 5 : 6)) : ((TM * TN == 2 && ACC2 && (PLAIN || TN == 2)) ? 4 : 1)) : 1)))
 void gemm_nt_kernel(GemmNTArgs p) {
   constexpr int BM = 64 * TM, BN = 64 * TN, LS = BK + 4;   // LS = 20 / 36: conflict-free ds_read_b128 (i*LS mod 64 distinct)
   constexpr int KQ = BK / 4, RP = 256 / KQ;                 // float4 per tile row, tile rows per load pass
@@ -933,12 +933,12 @@ extern "C" int stil_gemm_nt_config(const float* A, const float* W, int M, int N,
   // box: everything single-buffered 32-deep +1.0 % (8 of 8 pairs), plain K >= 256 alone -0.5 %, conv gathers alone +-0 --
   // the mix of LDS footprints of the two streams' kernels matters, not one kernel's own rate (profiles/r04_experiments.txt 12).
   const int bkd = (tune / 100) % 10;   // 0 automatic (= 3 where possible), 1 on (two LDS buffers), 2 off, 3 on with ONE LDS buffer
-  const bool bk32 = (bkd == 1 || bkd == 3 || bkd == 0) && (K % 32 == 0) && (KH * KW == 1 || srcC % 32 == 0) && (!a_bn || bkd != 1);
+  const bool bk32 = (bkd == 1 || bkd == 3 || (bkd == 0 && !a_bn)) && (K % 32 == 0) && (KH * KW == 1 || srcC % 32 == 0);
   const bool single = bk32 && (bkd == 3 || bkd == 0);
   const bool acc2 = tune / 1000 == 2 || (tune / 1000 == 0 && K >= 512);
   const bool vec = is_vec(A, lda) && (srcC % 4 == 0) && is_vec(W, ldb) && (K % 4 == 0);  // every 16-byte load aligned and entirely in or out
-  if (a_bn)   // operand-staging BatchNorm: 64x64 tiles; 16-deep double-buffered or 32-deep single-buffered k-tiles (see stil_gemm_nt)
-    return 11 + 100 * ((vec && bk32) ? 2 : 0) + 1000 * (acc2 ? 1 : 0) + 10000 * (vec ? 1 : 0) + 100000 * ((plain && KH * KW == 1) ? 1 : 0) + 1000000;
+  if (a_bn)   // operand-staging BatchNorm: 64x64 tiles, BK = 16 (see stil_gemm_nt)
+    return 11 + 1000 * (acc2 ? 1 : 0) + 10000 * (vec ? 1 : 0) + 100000 * ((plain && KH * KW == 1) ? 1 : 0) + 1000000;
   return variant + 100 * ((vec && bk32) ? (single ? 2 : 1) : 0) + 1000 * (acc2 ? 1 : 0) + 10000 * (vec ? 1 : 0) + 100000 * ((plain && KH * KW == 1) ? 1 : 0);
 }
 
@@ -1032,20 +1032,11 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   const bool vec = (cfg / 10000) % 10 == 1;
   rc = gemm_nt_attr();
   if (rc) return rc;
-  if (a_bn) {   // BatchNorm + ReLU of the producing layer applied while A is staged: 64x64 tiles, vector loads
-    STIL_REQUIRE(vec && (!bk32 || single) && mode == 0 && srcC % 16 == 0 && srcC <= 2048 && (tune % 100 == 0 || tune % 100 == 11),
+  if (a_bn) {   // BatchNorm + ReLU of the producing layer applied while A is staged: 64x64 tiles, vector loads, BK = 16 only
+    STIL_REQUIRE(vec && !bk32 && mode == 0 && srcC % 16 == 0 && srcC <= 2048 && (tune % 100 == 0 || tune % 100 == 11),
                  "stil_gemm_nt: a_bn runs 64x64 tiles only (tune %% 100 must be 0 or 11: the caller sizes colstats by "
                  "stil_gemm_nt_tile_rows) and needs 16-byte aligned operands, a forward gather, Cin %% 16 == 0 and Cin <= 2048 (Cin=%d)", srcC);
     const dim3 grid_(cdiv(M, 64) * cdiv(N, 64) * p.splits);
-    if (bk32) {   // 32-deep k-tiles in one LDS buffer (the automatic choice when Cin % 32 == 0)
-      const size_t lds_ = (size_t)64 * 2 * 36 * sizeof(float) + (size_t)3 * srcC * sizeof(float);
-      if (acc2 && plain) hipLaunchKernelGGL((gemm_nt_kernel<1, 1, 32, true, true, true, true, 1>), grid_, dim3(256), lds_, s, p);
-      else if (acc2) hipLaunchKernelGGL((gemm_nt_kernel<1, 1, 32, true, true, false, true, 1>), grid_, dim3(256), lds_, s, p);
-      else if (plain) hipLaunchKernelGGL((gemm_nt_kernel<1, 1, 32, true, false, true, true, 1>), grid_, dim3(256), lds_, s, p);
-      else hipLaunchKernelGGL((gemm_nt_kernel<1, 1, 32, true, false, false, true, 1>), grid_, dim3(256), lds_, s, p);
-      STIL_LAUNCH_CHECK();
-      return STIL_OK;
-    }
     const size_t lds_ = (size_t)2 * 64 * 2 * 20 * sizeof(float) + (size_t)3 * srcC * sizeof(float);
     if (acc2 && plain) hipLaunchKernelGGL((gemm_nt_kernel<1, 1, 16, true, true, true, true>), grid_, dim3(256), lds_, s, p);
     else if (acc2) hipLaunchKernelGGL((gemm_nt_kernel<1, 1, 16, true, true, false, true>), grid_, dim3(256), lds_, s, p);
