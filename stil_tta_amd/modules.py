@@ -264,11 +264,11 @@ class Block(nn.Module):  # models/Transformer.py:145-174 (pre-LN, dropouts p = 0
         a = ops.layernorm(x, self.norm1.weight, self.norm1.bias)
         qkv = ops.linear(a, self.attn.qkv.weight, self.attn.qkv.bias)
         o = ops.attention(qkv, self.attn.num_heads, [(0, T, 0, T)])
-        # proj + residual: the residual add rides in DropAdd (scale 1, no mask)
-        x = ops.drop_add(ops.linear(o, self.attn.proj.weight, self.attn.proj.bias), resid=x, rowlen=D)
+        # proj + residual and fc2 + residual: the sums ride in the GEMM epilogue (round 4; a pass of their own before)
+        x = ops.linear(o, self.attn.proj.weight, self.attn.proj.bias, resid=x.contiguous())
         m = ops.layernorm(x, self.norm2.weight, self.norm2.bias)
         m = ops.linear(m, self.mlp.fc1.weight, self.mlp.fc1.bias, act=2)
-        return ops.drop_add(ops.linear(m, self.mlp.fc2.weight, self.mlp.fc2.bias), resid=x, rowlen=D)
+        return ops.linear(m, self.mlp.fc2.weight, self.mlp.fc2.bias, resid=x)
 
 
 class TabularTransformerEncoder(nn.Module):  # models/Transformer.py:186-278

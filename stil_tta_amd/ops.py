@@ -299,19 +299,23 @@ def rng_mask(shape, p, seed, offset, device, step=None):
 
 # ------------------------------------------------------------------------------------------ Linear
 class LinearFn(torch.autograd.Function):
-    """y = act(x W^T + b)   nn.Linear (+ReLU / +GELU) -- e.g. models/Transformer.py:27-33."""
+    """y = act(x W^T + b) [+ resid]   nn.Linear (+ReLU / +GELU) -- e.g. models/Transformer.py:27-33; `resid` (act == 0 only): the
+    residual sum of a pre-LN transformer block rides in the GEMM epilogue (models/Transformer.py:170-173: x = x + attn(...),
+    x = x + mlp(...)) instead of in a pass of its own; same roundings in the same order."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act):
-        _chk(x, weight, bias)
+    def forward(ctx, x, weight, bias, act, resid=None):
+        _chk(x, weight, bias, resid)
         K = x.shape[-1]
         N = weight.shape[0]
         x2 = x.reshape(-1, K)
         M = x2.shape[0]
+        assert resid is None or (act == 0 and resid.numel() == M * N), "LinearFn: a residual needs act == 0 and the output's shape"
         pre = torch.empty((M, N), dtype=torch.float32, device=x.device) if act == 2 else None
-        y = gemm_nt(x2, weight, M, N, K, bias=bias, pre=pre, act=act)
+        y = gemm_nt(x2, weight, M, N, K, bias=bias, pre=pre, act=act, resid=None if resid is None else resid.reshape(M, N))
         ctx.act = act
         ctx.has_bias = bias is not None
+        ctx.has_resid = resid is not None
         if _trace is not None and act == 1 and any(ctx.needs_input_grad):
             _trace["relu"][id(weight)] = y.view(*x.shape[:-1], N)
         ctx.save_for_backward(x2, weight, bias, pre if act == 2 else (y if act == 1 else None))
@@ -338,11 +342,12 @@ class LinearFn(torch.autograd.Function):
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _grad_into(bias, lambda dst, acc: colsum(g, dst, M, N, accumulate=acc))
-        return dx, dw, db, None
+        dres = gy if (ctx.has_resid and ctx.needs_input_grad[4]) else None   # the residual branch: identity
+        return dx, dw, db, None, dres
 
 
-def linear(x, weight, bias=None, act=0):
-    return LinearFn.apply(x, weight, bias, act)
+def linear(x, weight, bias=None, act=0, resid=None):
+    return LinearFn.apply(x, weight, bias, act, resid)
 
 
 class MatmulNTFn(torch.autograd.Function):

@@ -450,6 +450,14 @@ def test_linear_fn(ops, act):
     z = ops.linear(xd, wd, bd, act)
     z.backward(dev(gy))
     close(z, y); close(xd.grad, x.grad, name="dx"); close(wd.grad, w.grad, name="dw"); close(bd.grad, b.grad, name="db")
+    if act == 0:   # the residual sum of a transformer block in the GEMM epilogue: bit for bit the separate add, identity gradient
+        r = torch.randn(6, 11, 70, generator=g)
+        rd = dev(r).requires_grad_()
+        xd2, wd2, bd2 = dev(x.detach()).requires_grad_(), dev(w.detach()).requires_grad_(), dev(b.detach()).requires_grad_()
+        z2 = ops.linear(xd2, wd2, bd2, 0, resid=rd)
+        z2.backward(dev(gy))
+        assert torch.equal(z2.detach(), (ops.linear(xd, wd, bd, 0).detach() + rd.detach())) and torch.equal(rd.grad, dev(gy))
+        assert torch.equal(xd2.grad, xd.grad) and torch.equal(wd2.grad, wd.grad) and torch.equal(bd2.grad, bd.grad)
 
 
 @pytest.mark.parametrize("cat,ncon", [([3, 4, 5, 2, 6], 6), ([], 5), ([4, 4], 0)])
