@@ -264,11 +264,16 @@ class Block(nn.Module):  # models/Transformer.py:145-174 (pre-LN, dropouts p = 0
         a = ops.layernorm(x, self.norm1.weight, self.norm1.bias)
         qkv = ops.linear(a, self.attn.qkv.weight, self.attn.qkv.bias)
         o = ops.attention(qkv, self.attn.num_heads, [(0, T, 0, T)])
-        # proj + residual and fc2 + residual: the sums ride in the GEMM epilogue (round 4; a pass of their own before)
-        x = ops.linear(o, self.attn.proj.weight, self.attn.proj.bias, resid=x.contiguous())
+        # proj + residual and fc2 + residual: the sums ride in the GEMM epilogue (round 4; STIL_LINEAR_RESID=0: a pass of their own)
+        if ops._LINEAR_RESID:
+            x = ops.linear(o, self.attn.proj.weight, self.attn.proj.bias, resid=x.contiguous())
+        else:
+            x = ops.drop_add(ops.linear(o, self.attn.proj.weight, self.attn.proj.bias), resid=x, rowlen=D)
         m = ops.layernorm(x, self.norm2.weight, self.norm2.bias)
         m = ops.linear(m, self.mlp.fc1.weight, self.mlp.fc1.bias, act=2)
-        return ops.linear(m, self.mlp.fc2.weight, self.mlp.fc2.bias, resid=x)
+        if ops._LINEAR_RESID:
+            return ops.linear(m, self.mlp.fc2.weight, self.mlp.fc2.bias, resid=x)
+        return ops.drop_add(ops.linear(m, self.mlp.fc2.weight, self.mlp.fc2.bias), resid=x, rowlen=D)
 
 
 class TabularTransformerEncoder(nn.Module):  # models/Transformer.py:186-278

@@ -384,6 +384,7 @@ _BN_EPILOGUE_STATS = __import__("os").environ.get("STIL_BN_EPILOGUE_STATS", "1")
 _BN_DEFER = __import__("os").environ.get("STIL_BN_DEFER", "1") != "0"
 _PREMASK = __import__("os").environ.get("STIL_PREMASK", "1") != "0"   # residual gradients leave the next block's dgrad GEMM pre-masked
 _BN_BWD_EPILOGUE = __import__("os").environ.get("STIL_BN_BWD_EPILOGUE", "1") != "0"   # BatchNorm-backward sums in the producing GEMM's epilogue
+_LINEAR_RESID = __import__("os").environ.get("STIL_LINEAR_RESID", "1") != "0"   # transformer residual sums in the Linear GEMM's epilogue
 
 
 def can_defer_bn(Cout: int) -> bool:
