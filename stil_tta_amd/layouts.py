@@ -11,9 +11,8 @@ foreign callers).  Pure data movement: bit-identical operands.
 """
 from __future__ import annotations
 
-import ctypes
 import struct
-from typing import Dict, List, Optional, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 import torch.nn as nn
