@@ -146,6 +146,8 @@ def launch_ranks(a) -> int:
     import socket
     import subprocess
     import tempfile
+    ndev = int(os.environ.get("STIL_FAKE_DEVICE_COUNT") or torch.cuda.device_count())   # counting devices does not initialise the GPU
+    launcher_check_devices(a.gpus, os.environ.get("STIL_DIST_BACKEND") or ("nccl" if ndev > 0 else "gloo"), ndev)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -201,24 +203,38 @@ def launch_ranks(a) -> int:
     return rc
 
 
-def check_devices(world: int, backend: str, device_count: int) -> bool:
-    """One GPU per rank.  Under RCCL ("nccl") fewer devices than ranks is an error named here, before the rendezvous
-    (RCCL would refuse two ranks on one device much later, with an opaque message).  Under gloo ranks MAY share a device
-    (the one-GPU test box): returns True then, and the bench prints `roofline: null` -- HIP events around a launch then also
-    span the other process's time slices and price nothing."""
-    if device_count >= world:
-        return False
+def check_devices(world: int, backend: str, device_count: int, local=None, env=None) -> bool:
+    """One GPU per rank.  Under RCCL ("nccl") a rank that would share its device is an error named here, before the rendezvous
+    (RCCL would refuse two ranks on one device much later, with an opaque message); which launch styles are accepted is
+    driver.pick_device's rule (every GPU visible to every rank, or one visible GPU per rank; LOCAL_WORLD_SIZE only when the
+    launcher exports it, never WORLD_SIZE).  Under gloo ranks MAY share a device (the one-GPU test box): returns True then, and
+    the bench prints `roofline: null` -- HIP events around a launch then also span the other process's time slices."""
+    from stil_tta_amd.driver import pick_device
+    env = os.environ if env is None else env
+    local = int(env.get("LOCAL_RANK", "0")) if local is None else local
     if backend == "nccl":
-        raise SystemExit(f"bench.py: --gpus {world} needs {world} visible GPUs for the RCCL backend, found {device_count} "
+        try:
+            pick_device(backend, local, device_count, env)
+        except RuntimeError as e:
+            raise SystemExit(f"bench.py: --gpus {world}: {e}")
+        return False
+    lws = env.get("LOCAL_WORLD_SIZE")
+    return device_count < (int(lws) if lws else world)
+
+
+def launcher_check_devices(n: int, backend: str, device_count: int) -> None:
+    """bench.py --gpus N as its own launcher: every rank inherits THIS process's device visibility, so N ranks under RCCL need N
+    visible GPUs here (a per-rank mask cannot exist: the launcher sets none)."""
+    if backend == "nccl" and device_count < n:
+        raise SystemExit(f"bench.py: --gpus {n} needs {n} visible GPUs for the RCCL backend, found {device_count} "
                          f"(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?); one process per GPU, ranks never share a device")
-    return True
 
 
 def launch_check(a):
     """The bench protocol with an empty step: rendezvous (gloo), barrier, K timed no-op steps, barrier, MAX over ranks, rank 0
     prints the line.  No GPU and no model: what it checks is that `--gpus N` really yields an N-rank job."""
     from stil_tta_amd.driver import init_distributed
-    if os.environ.get("STIL_FAKE_DEVICE_COUNT"):     # TEST ONLY: the "too few devices" refusal without a GPU
+    if os.environ.get("STIL_FAKE_DEVICE_COUNT"):     # TEST ONLY: the "ranks would share a device" refusal without a GPU
         check_devices(int(os.environ.get("WORLD_SIZE", "1")), os.environ.get("STIL_DIST_BACKEND") or "nccl", int(os.environ["STIL_FAKE_DEVICE_COUNT"]))
     rank, world, local = init_distributed(backend="gloo", timeout_s=a.launch_timeout)
     kind, _, who = a.launch_fault.partition(":")
@@ -418,9 +434,13 @@ def main():
                 pdir = os.path.join(ROOT, "profiles")
                 pmc = sorted(f for f in os.listdir(pdir) if f.endswith("pmc_traffic.json"))
                 tj = json.load(open(os.path.join(pdir, pmc[-1]))) if pmc else None
-                if tj and tj["kernel"] == kname and tj.get("kernel_source_sha") == sha and a.batch == 256 and a.img == 224:
+                # quoted only while it describes THESE launches: same kernel, same sources (kernels + the host files that compose a
+                # launch, _lib.source_hash) and -- belt and braces -- the same algorithmic bytes per launch as this run's
+                alg_ok = tj is not None and (tj.get("algorithmic_bytes_per_launch") is None or
+                                             abs(tj["algorithmic_bytes_per_launch"] - roof["algorithmic_bytes"]) <= 0.005 * roof["algorithmic_bytes"])
+                if tj and tj["kernel"] == kname and tj.get("kernel_source_sha") == sha and alg_ok and a.batch == 256 and a.img == 224 and a.variant == "dvm":
                     roof["traffic"] = round(tj["bytes_per_launch"])
-                    roof["traffic_source"] = f"profiles/{pmc[-1]} (kernel sources {sha})"
+                    roof["traffic_source"] = f"profiles/{pmc[-1]} (sources {sha})"
                 mu = sorted(f for f in os.listdir(pdir) if f.endswith("mfma_util.json"))
                 uj = json.load(open(os.path.join(pdir, mu[-1]))) if mu else None
                 if uj and kname in uj.get("kernels", {}) and uj.get("kernel_source_sha") == sha and a.batch == 256 and a.img == 224:

@@ -46,15 +46,24 @@ def parse_header(path: str = HEADER):
     return protos
 
 
+# host files that decide WHAT a launch carries (operands, epilogue forms, which layers fuse what): a profiler summary taken
+# before a change to one of them no longer describes the launches the bench times
+_HOST_HASHED = ("ops.py", "modules.py", "layouts.py", "stil_model.py", "flat.py", "saint.py")
+
+
 def source_hash() -> str:
-    """Content hash of the kernel sources (csrc/*.hip, *.h): stamps profiler summaries under profiles/ with the build they
-    were taken on (the GPU box has no .git to ask), so that bench.py quotes them only while the kernels are unchanged."""
+    """Content hash of the kernel sources (csrc/*.hip, *.h) AND of the host files that decide what a launch carries
+    (_HOST_HASHED): stamps profiler summaries under profiles/ with the build they were taken on (the GPU box has no .git to
+    ask), so that bench.py quotes them only while kernels and launch composition are unchanged."""
     import hashlib
     h = hashlib.sha256()
     for f in sorted(os.listdir(CSRC)):
         if f.endswith((".hip", ".h")):
             h.update(f.encode())
             h.update(open(os.path.join(CSRC, f), "rb").read())
+    for f in _HOST_HASHED:
+        h.update(f.encode())
+        h.update(open(os.path.join(_HERE, f), "rb").read())
     return h.hexdigest()[:12]
 
 

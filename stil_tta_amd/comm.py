@@ -327,6 +327,7 @@ def broadcast_state(model, optimizer=None):
         return
     model.setup_device()
     f = model.flat
+    f.invalidate_layouts()      # the slabs are about to be overwritten: no operand layout derived from them survives
     for t in (f.params, f.ema, f.exp_avg, f.exp_avg_sq, f.steps):
         dist.broadcast(t, src=0)
     for b in list(f.s_counters) + list(f.t_counters):

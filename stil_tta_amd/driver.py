@@ -44,11 +44,45 @@ def host_cpu_share() -> int:
     return max(1, n)
 
 
+def pick_device(backend: str, local: int, ndev: int, env=None) -> int:
+    """The device index of this rank, or a RuntimeError that names the cause when two ranks of the RCCL backend would share a
+    device (RCCL refuses that much later, with an opaque message).  Launch styles accepted under "nccl":
+      * one process per GPU of the node, every GPU visible to every rank (torch.distributed.run, bench.py --gpus N): LOCAL_RANK
+        -> GPU; LOCAL_RANK must be < the visible devices and, when the launcher exports LOCAL_WORLD_SIZE, so must be the devices;
+      * ONE visible GPU per rank (SLURM --gpus-per-task=1, per-rank HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES masks): device 0,
+        whatever LOCAL_RANK is -- recognised by a visibility variable in the rank's environment, or by a launcher that exports no
+        LOCAL_WORLD_SIZE (srun, mpirun);
+      * multi-node launchers that do not export LOCAL_WORLD_SIZE: only LOCAL_RANK < devices is checked (WORLD_SIZE counts the
+        ranks of every node and says nothing about this one).
+    gloo ranks may share a device (the one-GPU test box): LOCAL_RANK modulo the device count."""
+    env = os.environ if env is None else env
+    if ndev <= 0:
+        return -1
+    if backend != "nccl":
+        return local % ndev
+    lws = env.get("LOCAL_WORLD_SIZE")
+    lws = int(lws) if lws not in (None, "") else None
+    masked = any(env.get(v) not in (None, "") for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+    if ndev == 1:
+        if lws is not None and lws > 1 and not masked:
+            raise RuntimeError(f"init_distributed: {lws} local ranks on the RCCL backend but ONE visible GPU and no per-rank visibility "
+                               f"mask (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES): the ranks would share the device "
+                               f"(LOCAL_RANK={local}); one process per GPU")
+        return 0
+    if local >= ndev:
+        raise RuntimeError(f"init_distributed: LOCAL_RANK={local} on the RCCL backend needs more than the {ndev} visible GPUs; "
+                           f"one process per GPU, ranks never share a device")
+    if lws is not None and ndev < lws:
+        raise RuntimeError(f"init_distributed: {lws} local rank(s) on the RCCL backend need {lws} visible GPUs, found {ndev} "
+                           f"(LOCAL_RANK={local}); one process per GPU, ranks never share a device")
+    return local
+
+
 def init_distributed(backend: Optional[str] = None, timeout_s: Optional[float] = None):
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run). Returns (rank, world, local_rank).
     `timeout_s` (default STIL_DIST_TIMEOUT_S or 900): the process group's timeout -- a rank that never reaches the rendezvous
-    or a collective makes the others RAISE after that long instead of waiting for the job's outer limit.  Under the RCCL
-    backend every rank needs its own GPU: fewer visible devices than LOCAL_WORLD_SIZE is refused here by name."""
+    or a collective ends the job after that long instead of waiting for the job's outer limit (gloo raises in the waiting ranks;
+    under RCCL the watchdog ABORTS the process).  Under the RCCL backend every rank needs its own GPU (`pick_device`)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -58,14 +92,12 @@ def init_distributed(backend: Optional[str] = None, timeout_s: Optional[float] =
         if backend is None:  # "nccl" is RCCL on ROCm; STIL_DIST_BACKEND=gloo lets several ranks share one GPU (tests)
             backend = os.environ.get("STIL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         ndev = torch.cuda.device_count()
+        if os.environ.get("STIL_FAKE_DEVICE_COUNT") and backend == "nccl":   # TEST ONLY: the refusals without a GPU
+            pick_device(backend, local, int(os.environ["STIL_FAKE_DEVICE_COUNT"]))
         if backend == "nccl":
-            need = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-            if ndev < need or local >= ndev:
-                raise RuntimeError(f"init_distributed: {need} local rank(s) on the RCCL backend need {need} visible GPUs, found {ndev} "
-                                   f"(LOCAL_RANK={local}); one process per GPU, ranks never share a device")
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(pick_device(backend, local, ndev))
         elif ndev > 0 and torch.cuda.is_available():
-            torch.cuda.set_device(local % ndev)        # gloo: the ranks of a test may share the one GPU of the box
+            torch.cuda.set_device(pick_device(backend, local, ndev))        # gloo: the ranks of a test may share the one GPU of the box
         import datetime
         if timeout_s is None:
             timeout_s = float(os.environ.get("STIL_DIST_TIMEOUT_S", "900"))

@@ -121,7 +121,10 @@ class WeightLayouts:
             self.params.append(param)
         self.fresh = False
         self.event = None             # set by refresh(publish=True)
-        self.waited = set()
+        self.waited = set()           # (device index, stream id) of the streams that have waited for `event`
+        self.version = -1             # slab._version at the last refresh
+        self.pversion = {}            # id(param) -> param._version at the last refresh
+        self.captured = False         # the last refresh was recorded inside a hipGraph capture
 
     def _inside(self, w) -> bool:
         b = self.slab.data_ptr()
@@ -139,8 +142,21 @@ class WeightLayouts:
             st = torch.cuda.current_stream(self.slab.device)
             self.event = torch.cuda.Event()
             self.event.record(st)
-            self.waited = {st.cuda_stream}
+            self.waited = {(st.device_index, st.stream_id)}
+        # freshness is tied to the DATA, not only to the call sites that remember to invalidate: writes to the slab or to a
+        # parameter that go through PyTorch (checkpoint restores, collectives into the slab, tests) move their version counters
+        self.version = self.slab._version
+        self.pversion = {id(p): p._version for p in self.params}
+        self.captured = torch.cuda.is_current_stream_capturing()
         self.fresh = True
+
+    def current(self, param) -> bool:
+        """May `param`'s views be used now?  (ops.cached_layout)"""
+        if not self.fresh or self.slab._version != self.version or param._version != self.pversion.get(id(param), -2):
+            return False
+        if self.captured and not torch.cuda.is_current_stream_capturing():
+            return False      # recorded in a capture: outside it neither the views' producer nor its event is ordered before us
+        return True
 
     def invalidate(self):
         """The weights are about to change (optimizer step, EMA update, load_state_dict): operators fall back to their own

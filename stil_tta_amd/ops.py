@@ -36,38 +36,41 @@ def _chk(*ts):
 
 
 class _Workspace:
-    """One grow-only scratch buffer per (device, stream): launches of one stream are ordered, so reuse is safe."""
+    """One grow-only scratch buffer per (device, stream): launches of one stream are ordered, so reuse is safe.
+    A buffer that was handed out while a hipGraph was being captured is baked into that graph by address: it is never freed
+    (a later regrowth keeps it alive in `pinned`), so replays never write into memory the allocator has given to someone else."""
+    zero = False
 
     def __init__(self):
         self.buf = {}
+        self.captured = set()    # keys whose current buffer a captured graph may hold
+        self.pinned = []         # superseded buffers a captured graph may still address
 
     def get(self, nbytes: int, device) -> torch.Tensor:
         nbytes = max(int(nbytes), 256)
-        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        st = torch.cuda.current_stream(device)
+        key = (device, st.stream_id, st.cuda_stream)
         b = self.buf.get(key)
+        capturing = torch.cuda.is_current_stream_capturing()
         if b is None or b.numel() < nbytes:
-            b = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+            if b is not None and key in self.captured:
+                self.pinned.append(b)
+                self.captured.discard(key)
+            n = int(nbytes * (1.5 if self.zero else 1.25)) + 4096
+            b = (torch.zeros if self.zero else torch.empty)(n, dtype=torch.uint8, device=device)
             self.buf[key] = b
+        if capturing:
+            self.captured.add(key)
         return b
 
 
 _ws = _Workspace()
 
 
-class _SplitWorkspace:
+class _SplitWorkspace(_Workspace):
     """Split-K workspace of stil_gemm_nt (arrival tickets + slabs), one per (device, stream), ZERO-initialised: the library leaves
     the tickets zero after every launch, so a buffer is zeroed once, when it is (re)allocated."""
-
-    def __init__(self):
-        self.buf = {}
-
-    def get(self, nbytes: int, device) -> torch.Tensor:
-        key = (device, torch.cuda.current_stream(device).cuda_stream)
-        b = self.buf.get(key)
-        if b is None or b.numel() < nbytes:
-            b = torch.zeros(int(nbytes * 1.5) + 4096, dtype=torch.uint8, device=device)
-            self.buf[key] = b
-        return b
+    zero = True
 
 
 _split_ws = _SplitWorkspace()
@@ -163,15 +166,19 @@ def _touch(param):
 
 def cached_layout(param, attr: str, key=None):
     """The per-step layout view of a weight (layouts.WeightLayouts: one launch per step for the whole model), or None when
-    the parameter has no plan or the plan is stale -- the caller then runs its own per-call layout kernel."""
+    the parameter has no plan or the plan is stale -- the caller then runs its own per-call layout kernel.  Stale = invalidated by
+    a mutator that goes around PyTorch (Adam / EMA kernels: flat.invalidate_layouts), OR the slab / the parameter has been written
+    through PyTorch since the refresh (their version counters moved: checkpoint restores, collectives, tests), OR the refresh
+    was recorded inside a hipGraph capture and this call is not part of one (its event cannot be waited for eagerly)."""
     plan = getattr(param, "_stil_layouts", None)
-    if plan is None or not plan.fresh:
+    if plan is None or not plan.current(param):
         return None
     if plan.event is not None:      # refreshed on another stream: this stream waits for it once
         st = torch.cuda.current_stream(plan.slab.device)
-        if st.cuda_stream not in plan.waited:
+        sk = (st.device_index, st.stream_id)
+        if sk not in plan.waited:
             st.wait_event(plan.event)
-            plan.waited.add(st.cuda_stream)
+            plan.waited.add(sk)
     v = getattr(param, attr, None)
     if v is None or key is None:
         return v
@@ -214,7 +221,9 @@ def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None,
     if L._prof is not None:  # bench bookkeeping: tile variant + ALGORITHMIC flops (strided dgrad gathers count the conv's flops)
         s2 = geom[7] * geom[7] if geom[9] == 1 else 1
         src = (M // (geom[3] * geom[4])) * geom[0] * geom[1] * geom[2]  # gather source (each element fetched once, ideally)
-        nbytes = 4.0 * (src + N * K + M * N * (1 + (resid is not None) + (pre is not None)))
+        # every operand once: gather source, weights, the output, and the epilogue's reads / extra stores (residual, ReLU mask of the
+        # block output, the raw conv output the BatchNorm-backward sums are taken against, the stored pre-activation)
+        nbytes = 4.0 * (src + N * K + M * N * (1 + (resid is not None) + (pre is not None) + (relu_mask is not None) + (bstats is not None)))
         plain = int(geom[5] * geom[6] == 1 and geom[7] == 1 and pads == (0, 0) and geom[9] == 0 and outmap[0] == 1
                     and geom[0] == geom[3] and geom[1] == geom[4])
         cfg = L.gemm_nt_config(_p(A), _p(W), M, N, K, lda, ldb, geom[2], geom[5], geom[6], plain, int(a_bn is not None), TUNE["gemm"])
@@ -555,7 +564,7 @@ class ConvBnActFn(torch.autograd.Function):
                 bs = None
                 sc_ = ctx.bstat_send
                 Min = Nb * H * W_
-                if sc_ is not None and "y" in sc_ and Cin % 4 == 0 and (sc_["mode"] == 2 or (zmask is not None and sc_.get("premask") is cell)) \
+                if sc_ is not None and "y" in sc_ and Cin % 4 == 0 and _bstats_tune_ok() and (sc_["mode"] == 2 or (zmask is not None and sc_.get("premask") is cell)) \
                         and (stride == 1 or ga is None) and tuple(sc_["y"].shape) == (Min, Cin) \
                         and lib().gemm_nt_bstats_ok(None, Cin, Cin, _p(ga), Cin, _p(zmask), Cin, _p(sc_["y"])):
                     nt_ = _bstat_tiles(Nb, H, W_, k, stride, pad)
@@ -584,6 +593,13 @@ class ConvBnActFn(torch.autograd.Function):
             dw = wgrad_param(w, dy, x, M, Cout, k * k * Cin, geom=gw, x_bn=xstats)
         return (dx, dw, (None if gslot is not None else dgamma), (None if bslot is not None else dbeta), None, None, None,
                 dres, None, None, None, None, None, None, None, None, None, None, None, None, None)
+
+
+def _bstats_tune_ok() -> bool:
+    """`bstats` rides in the 16-byte epilogue of 64x64 tiles only (stil_gemm_nt's STIL_REQUIRE): with a forced tile variant or the
+    scalar epilogue (STIL_GEMM_TUNE, A/B measurements) the caller must take bn_train_bwd's own reduction pass instead."""
+    t = TUNE["gemm"]
+    return t < 10000 and t % 100 in (0, 11)
 
 
 def _bstat_tiles(Nb, H, W_, k, stride, pad):

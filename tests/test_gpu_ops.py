@@ -843,6 +843,25 @@ def test_weight_layout_plan_equals_the_per_call_layouts_bit_for_bit(ops):
                 assert torch.equal(cached_layout(w, "_stil_wphase", (py, px)), ws), (k, py, px)
     plan.invalidate()
     assert cached_layout(net[0].weight, "_stil_wd") is None
+    # freshness is tied to the DATA (round-4 advisor finding): a writer that goes around invalidate() -- a collective or a
+    # checkpoint restore copying straight into the slab, an in-place update of one parameter -- makes the views stale too
+    plan.refresh()
+    assert cached_layout(net[0].weight, "_stil_wd") is not None
+    slab[:16].add_(1.0)                                   # e.g. comm.broadcast_state -> dist.broadcast(flat.params)
+    assert cached_layout(net[0].weight, "_stil_wd") is None and cached_layout(net[2].weight, "_stil_wd") is None
+    plan.refresh()
+    assert torch.equal(cached_layout(net[0].weight, "_stil_wf")[0, :16], net[0].weight.detach().permute(0, 2, 3, 1).reshape(32, -1)[0, :16])
+    with torch.no_grad():
+        net[2].weight.mul_(2.0)                           # one parameter written through PyTorch
+    assert cached_layout(net[2].weight, "_stil_wd") is None and cached_layout(net[0].weight, "_stil_wd") is not None
+    plan.refresh()
+    assert torch.equal(cached_layout(net[2].weight, "_stil_wd"), ops.transpose(net[2].weight.detach().reshape(24, 64)))
+    # a refresh recorded inside a hipGraph capture is not usable by eager callers afterwards (its event was never recorded eagerly)
+    plan.captured = True
+    assert cached_layout(net[0].weight, "_stil_wd") is None
+    plan.captured = False
+    assert cached_layout(net[0].weight, "_stil_wd") is not None
+    plan.invalidate()
     # the whole step with and without the plan
     import os
     from stil_tta_amd import STiLModel

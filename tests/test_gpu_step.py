@@ -97,32 +97,40 @@ def _check_flips(flips):
         assert mag <= NORTH_STAR * (1.0 + scale), f"decision {t}: {n} units differ from float64 with |pre-activation| up to {mag:.2e} (tensor max {scale:.2e})"
 
 
+# Tensors whose fp32 yardstick is taken per MODULE (the larger of the weight's and the bias' e32) instead of per tensor: the ITC
+# projection heads only.  Their bias gradient is the column sum of rows that cancel to 7 % of their norm (tests/tools/
+# itc_conditioning.py), so ONE fp32 realisation of it is itself noise -- the reference's own fp32 path lands anywhere in
+# 4.8e-5 .. 6.6e-5 on projector_imaging.bias at the BASELINE shape while the weight of the same head, fed by the same incoming
+# gradient, sits at 1.6e-4 (measured decomposition: DESIGN.md section 2).  Every other tensor keeps the per-tensor bound.
+MODULE_YARDSTICK = ("projector_imaging", "projector_tabular")
+
+
 def _grad_errors(params, g64, e32_of):
     """relative L2 error of every device gradient against the float64 oracle evaluated on the device's own
-    decisions, judged against the reference's own fp32-vs-fp64 distance e32: err <= 3 * e32 + 1e-4 for EVERY tensor.
-    e32 is taken per MODULE (the larger of its weight's and its bias'): both are functions of the same incoming gradient, whose
-    fp32 noise shows in both, and a single tensor's realisation of that noise can come out low by chance -- at the BASELINE shape
-    the reference's own fp32 path is 6.6e-5 from float64 on projector_imaging.bias and 1.6e-4 on projector_imaging.weight, the
-    device 2.7e-4 and 1.9e-4, and replacing every operator of the ITC path by ATen's leaves the device's numbers where they
-    are (tests/tools/itc_noise.py: the error is the features' rounding noise through an ill-conditioned head, not an operator)."""
+    decisions, judged against the reference's own fp32-vs-fp64 distance e32 OF THAT TENSOR: err <= 3 * e32 + 1e-4.
+    For the allow-listed ill-conditioned heads (MODULE_YARDSTICK) e32 is the larger of the module's weight's and bias'; the
+    per-tensor ratio of those tensors is printed beside it so that drift stays visible."""
     mod = lambda k: k.rsplit(".", 1)[0]
     e32s = {k: e32_of(k) for k, g in g64.items() if g is not None}
     e_mod = {}
     for k, e in e32s.items():
         e_mod[mod(k)] = max(e_mod.get(mod(k), 0.0), e)
-    bad, ratios, named = [], [], []
+    bad, ratios, named, listed = [], [], [], []
     for k, g in g64.items():
         p = params[k]
         if g is None:
             assert not p._stil_touched, k
             continue
-        e32 = e_mod[mod(k)]
+        e32 = e_mod[mod(k)] if mod(k) in MODULE_YARDSTICK else e32s[k]
         err = float((p._gslot.cpu().double() - g).norm() / (g.norm() + 1e-30))
         ratios.append(err / (3 * e32 + 1e-4))
-        named.append((ratios[-1], k, f"{err:.2e}", f"e32 {e32s[k]:.2e} (module {e32:.2e})"))
+        named.append((ratios[-1], k, f"{err:.2e}", f"e32 {e32s[k]:.2e}"))
+        if mod(k) in MODULE_YARDSTICK:
+            listed.append((k, f"err {err:.2e}", f"per-tensor ratio {err / (3 * e32s[k] + 1e-4):.2f}", f"per-module ratio {ratios[-1]:.2f}"))
         if err > 3 * e32 + 1e-4:
             bad.append(("grad " + k, err, e32))
     print("closest to their bound:", sorted(named, reverse=True)[:4])
+    print("per-module yardstick (ITC heads):", listed)
     return bad, ratios
 
 
@@ -430,30 +438,36 @@ def test_baseline_shape_step_matches_oracle():
     assert not bad, f"{len(bad)} mismatches, first: {bad[:10]}"
 
 
-def test_configs1_full_size_forward_matches_oracle():
-    """BASELINE.json configs[1] at FULL size -- ResNet-50, 224 px, 16 categorical + 48 continuous columns, K = 286, B = 256
-    (32 labelled + 224 unlabelled), pseudo-label phase, injected mask_random and MI-layer dropout masks: every forward
-    quantity of STiLModel.training_step (:228-345: logits, features, teacher outputs, CGPL / PGLS pseudo-labels, all 11 loss
-    terms, class sums) through the HIP path against oracle.training_step on the host cores (no_grad: two oracle passes,
-    the first one also crafts the heads), and EXACT CGPL case ids / mask1.  Backward at this size is covered by the B = 32
-    oracle test above and the B = 256 properties below."""
+_CASE_CACHE = {}
+
+
+def _full_size_case(key, over, B, seeds, boost=(0.3, 28.0), scale=6.0, min_gap=2e-4, min_cases=3):
+    """A bench-shape configuration with crafted heads (mixed CGPL cases, th1 in the widest gap of the confidence ranking so that
+    no rounding can flip mask1): -> hp, sd0 (the state the device gets), batch, mask_random, MI masks, o (oracle.training_step
+    on the host cores under no_grad).  Two oracle passes; cached per key (the forward and the backward test of one
+    configuration share them).  The head coupling / centring is oracle.make_golden.craft_heads' with its oracle pass shared."""
+    if key in _CASE_CACHE:
+        return _CASE_CACHE[key]
     from oracle.make_golden import randomize_state, make_mi_masks
-    fl = [8] * 16 + [1] * 48
-    B, K = 256, 286
-    hp = O.default_hparams(img_size=224, field_lengths=fl, num_classes=K, batch_size=B, start_epoch=0, th1=0.5)
-    sd = randomize_state(O.init_state(hp, seed=31), seed=32)
-    g = torch.Generator().manual_seed(33)
+    hp = O.default_hparams(batch_size=B, start_epoch=0, th1=0.5, **over)
+    K = hp.num_classes
+    sd = randomize_state(O.init_state(hp, seed=seeds[0]), seed=seeds[1])
+    g = torch.Generator().manual_seed(seeds[2])
     sd["prototypes"] = torch.nn.functional.normalize(torch.randn(K, hp.projection_dim, generator=g))
     batch = O.synthetic_batch(hp, B, seed=2022)
     B_u = len(batch["u"][2])
     mr = torch.rand(B_u, generator=g).ge(0.5)
-    mm = {0: make_mi_masks(B, 49, len(fl), 512, 4, hp.mi_drop, seed=6)}
-    # the head coupling / centring of oracle.make_golden.craft_heads (mixed CGPL cases), with its oracle pass shared:
+    Ni, Nt = (hp.img_size // 32) ** 2, len(hp.field_lengths)
+    mm = {0: make_mi_masks(B, Ni, Nt, hp.multimodal_embedding_dim, 4, hp.mi_drop, seed=seeds[3])}
+    if hp.tabular_encoder == "saint":  # FF dropout p = 0.8 of the SAINT column / row feed-forwards (oracle.make_golden.build_case)
+        g2 = torch.Generator().manual_seed(seeds[3] + 1)
+        nf = Nt + 1
+        mm["saint"] = {"ff_col": torch.rand(B, nf, 4 * O.SAINT_DIM, generator=g2) >= hp.saint_ff_drop,
+                       "ff_row": torch.rand(1, B, 4 * O.SAINT_DIM * nf, generator=g2) >= hp.saint_ff_drop}
     C = hp.multimodal_embedding_dim
-    scale = 6.0
     for pre_ in ("model.", "ema."):
-        sd[pre_ + "classifier_multimodal.weight"][:, 512:1024] *= 0.3
-        sd[pre_ + "classifier_multimodal.weight"][:, 1024:] *= 28.0
+        sd[pre_ + "classifier_multimodal.weight"][:, C:2 * C] *= boost[0]
+        sd[pre_ + "classifier_multimodal.weight"][:, 2 * C:] *= boost[1]
         Wm = sd[pre_ + "classifier_multimodal.weight"]
         sd[pre_ + "classifier_imaging.weight"][:, :C] = Wm[:, :C]
         sd[pre_ + "classifier_tabular.weight"][:, :C] = Wm[:, 2 * C:]
@@ -461,8 +475,8 @@ def test_configs1_full_size_forward_matches_oracle():
         sd[pre_ + "classifier_tabular.weight"][:, C:] *= 0.2
     with torch.no_grad():
         o1 = O.training_step({k: v.clone() for k, v in sd.items()}, batch, hp, 1, mr, mm)
-    for nm, key in (("classifier_multimodal", "y_hat_m_e"), ("classifier_imaging", "y_hat_i_e"), ("classifier_tabular", "y_hat_t_e")):
-        mean = o1[key].mean(0)
+    for nm, key_ in (("classifier_multimodal", "y_hat_m_e"), ("classifier_imaging", "y_hat_i_e"), ("classifier_tabular", "y_hat_t_e")):
+        mean = o1[key_].mean(0)
         for pre_ in ("model.", "ema."):
             sd[pre_ + nm + ".weight"] *= scale
             sd[pre_ + nm + ".bias"] = (sd[pre_ + nm + ".bias"] - mean) * scale
@@ -477,15 +491,23 @@ def test_configs1_full_size_forward_matches_oracle():
     gaps = conf[lo + 1: B_u - lo + 1] - conf[lo: B_u - lo]
     j = int(gaps.argmax()) + lo
     hp.th1 = float((conf[j] + conf[j + 1]) / 2)
-    assert float(gaps.max()) > 2e-4, "no rounding-proof th1 on this batch"
+    assert float(gaps.max()) > min_gap, f"no rounding-proof th1 on this batch (widest gap {float(gaps.max()):.2e})"
     sd0 = {k: v.clone() for k, v in sd.items()}
     with torch.no_grad():
         o = O.training_step(sd, batch, hp, 1, mr, mm)
     assert float((o["prediction"] - pred).abs().max()) < 1e-3
     assert 0 < int(o["mask1"].sum()) < B_u
-    assert sum(int(o[c].sum()) > 0 for c in ("case1", "case2_i", "case2_t", "case3")) >= 3, "CGPL cases must be mixed"
+    assert sum(int(o[c].sum()) > 0 for c in ("case1", "case2_i", "case2_t", "case3")) >= min_cases, \
+        f"CGPL cases must be mixed: {[int(o[c].sum()) for c in ('case1', 'case2_i', 'case2_t', 'case3')]}"
+    _CASE_CACHE[key] = (hp, sd0, batch, mr, mm, o)
+    return _CASE_CACHE[key]
 
-    m = _make_model(hp, sd0)
+
+def _forward_vs_oracle(label, hp, sd0, batch, mr, mm, o):
+    """One no_grad training_step through the HIP path against the oracle's forward quantities (north-star 1e-4) and EXACT CGPL
+    case ids / mask1."""
+    B_u = len(batch["u"][2])
+    m = _make_model(hp, {k: v.clone() for k, v in sd0.items()})
     m.current_epoch = 1
     with torch.no_grad():
         m.training_step(_to_dev(batch), 0, mask_random=mr, mi_masks=mm)
@@ -499,9 +521,110 @@ def test_configs1_full_size_forward_matches_oracle():
         if d > NORTH_STAR:
             bad.append((k, d))
     _check_flags(m.last, o, B_u)
-    print(f"configs[1] full size: th1 = {hp.th1:.4f}, mask1 {int(o['mask1'].sum())}/{B_u}, cases "
+    print(f"{label}: th1 = {hp.th1:.4f}, mask1 {int(o['mask1'].sum())}/{B_u}, cases "
           f"{[int(o[c].sum()) for c in ('case1', 'case2_i', 'case2_t', 'case3')]}; beyond {TOL:g} (bar {NORTH_STAR:g}): {beyond}")
-    assert not bad, f"{len(bad)} forward quantities beyond the north-star 1e-4: {bad[:10]}"
+    assert not bad, f"{label}: {len(bad)} forward quantities beyond the north-star 1e-4: {bad[:10]}"
+    del m
+    torch.cuda.empty_cache()
+
+
+CONFIGS1 = dict(img_size=224, field_lengths=[8] * 16 + [1] * 48, num_classes=286)
+# configs[3] (config_dvm_STiL_SAINT.yaml) and configs[4] (config_cardiac_STiL.yaml deltas, as bench.py --variant cardiac) at the
+# shapes the round-4 profiles measured them on (profiles/r04z_{saint,cardiac64,cardiac16}_*)
+CONFIGS3 = dict(img_size=224, field_lengths=[8] * 16 + [1] * 48, num_classes=286, tabular_encoder="saint")
+CONFIGS4 = dict(img_size=128, field_lengths=[4] * 26 + [1] * 49, num_classes=2, target="CAD", rate_pseudo=0.95, ema_momentum=0.4, beta=1.0,
+                gamma=1.0, lr_eval=1e-3)
+
+
+def test_configs1_full_size_forward_matches_oracle():
+    """BASELINE.json configs[1] at FULL size -- ResNet-50, 224 px, 16 categorical + 48 continuous columns, K = 286, B = 256
+    (32 labelled + 224 unlabelled), pseudo-label phase, injected mask_random and MI-layer dropout masks: every forward
+    quantity of STiLModel.training_step (:228-345: logits, features, teacher outputs, CGPL / PGLS pseudo-labels, all 11 loss
+    terms, class sums) through the HIP path against oracle.training_step on the host cores (no_grad: two oracle passes,
+    the first one also crafts the heads), and EXACT CGPL case ids / mask1.  Backward at this size: the next test."""
+    _forward_vs_oracle("configs[1] full size", *_full_size_case("configs1_b256", CONFIGS1, 256, (31, 32, 33, 6)))
+
+
+def test_configs1_full_size_backward_matches_oracle():
+    """configs[1] at FULL size, the WHOLE optimisation step (STiLModel.py:228-386 + backward + Adam :557-570): B = 256 takes code
+    paths B = 32 never does (weight-gradient M-splits, > 256-tile BatchNorm finalisation in two launches, more XCD-remapped
+    tiles).  One device step (decisions exported), one fp32 oracle.full_step on the device's ReLU / max-pool decisions (about two
+    minutes on the box's 16 cores), then: EVERY gradient tensor relL2(device, fp32 oracle) <= 4 e32 + 1e-4, where e32 is the
+    REFERENCE's own fp32-vs-float64 distance of that tensor at this architecture (fixture dvm_r50_b32_224, per module) -- the
+    B = 32 test's bar (3 e32 + 1e-4 against float64) plus the fp32 oracle's own e32; BatchNorm running statistics, the EMA
+    teacher and the prototype accumulators at 5e-5; |delta Adam| <= 2.2 lr."""
+    from stil_tta_amd.driver import train_step
+    from stil_tta_amd.flat import StilAdam
+    hp, sd0, batch, mr, mm, o_fwd = _full_size_case("configs1_b256", CONFIGS1, 256, (31, 32, 33, 6))
+    fx = np.load(os.path.join(GOLD, "dvm_r50_b32_224.npz"))
+    m = _make_model(hp, {k: v.clone() for k, v in sd0.items()})
+    m.current_epoch = 1
+    with _trace_decisions() as trace:
+        train_step(m, StilAdam(m.flat, lr=hp.lr_eval), _to_dev(batch), mask_random=mr, mi_masks=mm)
+        torch.cuda.synchronize()
+        decisions = _device_decisions(m, trace)
+    params = _named_params(m)
+    gdev = {k: params[k]._gslot.detach().cpu().double() for k in params}
+    touched = {k: bool(params[k]._stil_touched) for k in params}
+    msd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    B_u = len(batch["u"][2])
+    flags = m.last["flags"].cpu()
+    del m, trace, params
+    torch.cuda.empty_cache()
+    sd = {k: v.clone() for k, v in sd0.items()}
+    with O.force_decisions(*decisions) as d:
+        o = O.full_step(sd, {}, 1, batch, hp, 1, mr, mm)
+    flips = {t: v for t, v in d.get("flips", {}).items() if v[0]}
+    _check_flips(flips)
+    cs = flags[:, 0]
+    assert torch.equal(cs == 1, o["case1"]) and torch.equal(cs == 2, o["case2_i"]) and torch.equal(cs == 3, o["case2_t"]) and torch.equal(cs == 4, o["case3"])
+    assert torch.equal(flags[:, 1].bool(), o["mask1"])
+    mod = lambda k: k.rsplit(".", 1)[0]
+    e_mod = {}
+    for k in o["grads"]:
+        if "gerr32_" + k in fx.files:
+            e_mod[mod(k)] = max(e_mod.get(mod(k), 0.0), float(fx["gerr32_" + k]))
+    bad, named = [], []
+    for k, g in o["grads"].items():
+        if g is None:
+            assert not touched[k], k
+            continue
+        e32 = e_mod[mod(k)]
+        err = float((gdev[k] - g.double()).norm() / (g.double().norm() + 1e-30))
+        named.append((err / (4 * e32 + 1e-4), k, f"{err:.2e}", f"e32 {e32:.2e}"))
+        if err > 4 * e32 + 1e-4:
+            bad.append(("grad " + k, err, e32))
+    ratios = [r[0] for r in named]
+    tr = set(O.trainable_keys(sd))
+    for k, v in sd.items():
+        if k in tr:
+            if float((msd[k] - v).abs().max()) > 2.2 * hp.lr_eval:
+                bad.append(("adam " + k,))
+        else:  # BN running statistics, the EMA teacher, prototype accumulators
+            ok, err = _close(msd[k].double().numpy(), v.double().numpy(), 5e-5)
+            if not ok:
+                bad.append(("state " + k, err))
+    print(f"configs[1] full size, backward: gradient error / (4*e32 + 1e-4): median {np.median(ratios):.3f}, p90 {np.percentile(ratios, 90):.3f}, "
+          f"max {np.max(ratios):.3f}; closest to their bound: {sorted(named, reverse=True)[:4]}; the fp32 oracle decides differently on "
+          f"{ {t: v[0] for t, v in flips.items()} }")
+    assert not bad, f"{len(bad)} mismatches, first: {bad[:10]}"
+
+
+def test_configs3_saint_bench_shape_forward_matches_oracle():
+    """BASELINE.json configs[3] (config_dvm_STiL_SAINT: SAINT tabular encoder) at the shape bench.py --variant saint measures --
+    B = 256, 224 px, 16 categorical + 48 continuous columns, K = 286: the intersample attention runs over the 256 rows of
+    65 x 32 features (SAINT/model_util.py:111-129, STiLModel_SAINT_backbone.py:159-184), the golden case only over 16 rows of
+    8 x 32.  Forward of the whole step against the oracle (no_grad), exact CGPL ids / mask1."""
+    _forward_vs_oracle("configs[3] SAINT, B=256", *_full_size_case("configs3_b256", CONFIGS3, 256, (41, 42, 43, 7)))
+
+
+@pytest.mark.parametrize("B", [64, 16])
+def test_configs4_cardiac_bench_shape_forward_matches_oracle(B):
+    """BASELINE.json configs[4] (config_cardiac_STiL.yaml: K = 2, SimCLR projection heads, rate_pseudo 0.95, EMA momentum 0.4) at
+    the shapes the cardiac benches run -- 128 px, 26 categorical + 49 continuous columns, B = 64 (one GPU) and B = 16 (the share
+    of one of the 4 GPUs the config names): forward of the whole step against the oracle (no_grad), exact CGPL ids / mask1.
+    With two classes `case3` (image and table agree against the multimodal head) is rare: two mixed cases are asked for."""
+    _forward_vs_oracle(f"configs[4] cardiac, B={B}", *_full_size_case(f"configs4_b{B}", CONFIGS4, B, (51 + B, 52, 53, 8), min_cases=2, min_gap=1e-4))
 
 
 def test_five_step_trajectory_matches_oracle():

