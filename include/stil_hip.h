@@ -238,9 +238,13 @@ int stil_scale_dev(const float* x, const float* g_dev, float c, float* out, long
 int stil_l2norm_fwd(const float* x, float* y, float* norms, int rows, int D, void* stream);
 int stil_l2norm_bwd(const float* g, const float* y, const float* norms, float* dx, int rows, int D,
                     void* stream);
-int stil_clip_fwd(const float* Z, float* lse, float* terms, float* loss, int B, float lam0, float lam1,
+/* CLIPLoss.forward on the logits Z = n0 n1^T / T (utils/clip_loss.py:34-38): lse = [2][B] row / column log-sum-exps, kept in
+ * DOUBLE -- the gradient dZ sums to zero over the whole matrix and the projector-bias gradient downstream is the image of
+ * that total through the embeddings' common component, so an lse error shared by all rows is amplified by the batch size
+ * (csrc/loss.hip); dZ is formed in double and rounded once. */
+int stil_clip_fwd(const float* Z, double* lse, float* terms, float* loss, int B, float lam0, float lam1,
                   void* stream);
-int stil_clip_bwd(const float* Z, const float* lse, const float* g_dev, float* dZ, int B, float lam0,
+int stil_clip_bwd(const float* Z, const double* lse, const float* g_dev, float* dZ, int B, float lam0,
                   float lam1, void* stream);
 int stil_club_fwd(const float* mu, const float* y, const float* ybar, float* rows_tmp, float* out2, int R,
                   int D, void* stream);

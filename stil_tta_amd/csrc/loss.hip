@@ -102,45 +102,65 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------- CLIP: row / column log-sum-exp of Z [B,B]
-__global__ __launch_bounds__(256) void lse_rows_kernel(const float* __restrict__ Z, float* __restrict__ lse, int R, int C) {
+// In DOUBLE.  The gradient dZ = g/B (lam0 (softmax_rows - I) + lam1 (softmax_cols - I)) sums to exactly zero over the whole
+// matrix, and the projector-bias gradient downstream is the image of that grand total through the COMMON component of the
+// embeddings (every row's dZ . n1 carries the batch-mean embedding): an error shared by all rows does not average out, it is
+// multiplied by the batch size.  With lse = m + logf(s) in fp32 every softmax row came out scaled by (1 - eta) with one eta of
+// ~0.6 ulp(lse) = 1.5e-7 for all rows and columns; elementwise that is 4.5e-8 of |dZ| -- and 2e-4 of projector_imaging.bias'
+// gradient (15x what ATen's fp32 path leaves there; tests/tools/itc_ladder.py, itc_noise.py, round-5 experiment log).  The
+// log-sum-exps and the probabilities are therefore formed in double and dZ is rounded ONCE: its error is the half-ulp of the
+// fp32 it is stored in (zero-mean, independent per element).  B^2 double exponentials: 65 k at B = 256, noise beside the step.
+__device__ __forceinline__ double block_sum_d(double v, double* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (l == 0) sh[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  for (int i = 0; i < nw; ++i) r += sh[i];  // fixed order: deterministic
+  return r;
+}
+__global__ __launch_bounds__(256) void lse_rows_kernel(const float* __restrict__ Z, double* __restrict__ lse, int R, int C) {
   __shared__ float red[16];
+  __shared__ double redd[16];
   const float* zr = Z + (long)blockIdx.x * C;
   float m = -INFINITY;
   for (int k = threadIdx.x; k < C; k += 256) m = fmaxf(m, zr[k]);
   m = block_max(m, red);
-  float s = 0.f;
-  for (int k = threadIdx.x; k < C; k += 256) s += expf(zr[k] - m);
-  s = block_sum(s, red);
-  if (threadIdx.x == 0) lse[blockIdx.x] = m + logf(s);
+  double s = 0.0;
+  for (int k = threadIdx.x; k < C; k += 256) s += exp((double)zr[k] - (double)m);
+  s = block_sum_d(s, redd);
+  if (threadIdx.x == 0) lse[blockIdx.x] = (double)m + log(s);
 }
-__global__ void lse_cols_kernel(const float* __restrict__ Z, float* __restrict__ lse, int R, int C) {
+__global__ void lse_cols_kernel(const float* __restrict__ Z, double* __restrict__ lse, int R, int C) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float m = -INFINITY;
   for (int r = 0; r < R; ++r) m = fmaxf(m, Z[(long)r * C + c]);
-  float s = 0.f;
-  for (int r = 0; r < R; ++r) s += expf(Z[(long)r * C + c] - m);
-  lse[c] = m + logf(s);
+  double s = 0.0;
+  for (int r = 0; r < R; ++r) s += exp((double)Z[(long)r * C + c] - (double)m);
+  lse[c] = (double)m + log(s);
 }
 // row_term[i] = lam0*(lse_r[i]-Z[i][i]) + lam1*(lse_c[i]-Z[i][i])
-__global__ void clip_terms_kernel(const float* __restrict__ Z, const float* __restrict__ lse_r,
-                                  const float* __restrict__ lse_c, float* __restrict__ terms, int B, float lam0,
+__global__ void clip_terms_kernel(const float* __restrict__ Z, const double* __restrict__ lse_r,
+                                  const double* __restrict__ lse_c, float* __restrict__ terms, int B, float lam0,
                                   float lam1) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
-  float d = Z[(long)i * B + i];
-  terms[i] = lam0 * (lse_r[i] - d) + lam1 * (lse_c[i] - d);
+  const double d = (double)Z[(long)i * B + i];
+  terms[i] = (float)((double)lam0 * (lse_r[i] - d) + (double)lam1 * (lse_c[i] - d));
 }
-// dZ[r,c] = g * ( lam0/B (exp(z-lse_r[r]) - I) + lam1/B (exp(z-lse_c[c]) - I) )
-__global__ void clip_dz_kernel(const float* __restrict__ Z, const float* __restrict__ lse_r,
-                               const float* __restrict__ lse_c, const float* __restrict__ g, float* __restrict__ dZ,
+// dZ[r,c] = g * ( lam0/B (exp(z-lse_r[r]) - I) + lam1/B (exp(z-lse_c[c]) - I) ), formed in double, rounded once
+__global__ void clip_dz_kernel(const float* __restrict__ Z, const double* __restrict__ lse_r,
+                               const double* __restrict__ lse_c, const float* __restrict__ g, float* __restrict__ dZ,
                                int B, float lam0, float lam1) {
   long n = (long)B * B;
-  const float gg = g[0] / (float)B;
+  const double gg = (double)g[0] / (double)B;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     int r = (int)(i / B), c = (int)(i - (long)r * B);
-    float z = Z[i], e = (r == c) ? 1.f : 0.f;
-    dZ[i] = gg * (lam0 * (expf(z - lse_r[r]) - e) + lam1 * (expf(z - lse_c[c]) - e));
+    const double z = (double)Z[i], e = (r == c) ? 1.0 : 0.0;
+    dZ[i] = (float)(gg * ((double)lam0 * (exp(z - lse_r[r]) - e) + (double)lam1 * (exp(z - lse_c[c]) - e)));
   }
 }
 
@@ -420,8 +440,8 @@ extern "C" int stil_l2norm_bwd(const float* g, const float* y, const float* norm
   return STIL_OK;
 }
 
-// Z: [B,B] logits (already / T). lse: [2,B] (rows, cols). terms: [B] scratch. loss: scalar.
-extern "C" int stil_clip_fwd(const float* Z, float* lse, float* terms, float* loss, int B, float lam0, float lam1,
+// Z: [B,B] logits (already / T). lse: [2,B] DOUBLES (rows, cols). terms: [B] scratch. loss: scalar.
+extern "C" int stil_clip_fwd(const float* Z, double* lse, float* terms, float* loss, int B, float lam0, float lam1,
                              void* stream) {
   STIL_REQUIRE(Z && lse && terms && loss && B > 0, "stil_clip_fwd: bad arguments");
   hipStream_t s = (hipStream_t)stream;
@@ -435,7 +455,7 @@ extern "C" int stil_clip_fwd(const float* Z, float* lse, float* terms, float* lo
   STIL_LAUNCH_CHECK();
   return STIL_OK;
 }
-extern "C" int stil_clip_bwd(const float* Z, const float* lse, const float* g_dev, float* dZ, int B, float lam0,
+extern "C" int stil_clip_bwd(const float* Z, const double* lse, const float* g_dev, float* dZ, int B, float lam0,
                              float lam1, void* stream) {
   STIL_REQUIRE(Z && lse && g_dev && dZ && B > 0, "stil_clip_bwd: bad arguments");
   hipLaunchKernelGGL(clip_dz_kernel, dim3(ew_grid2((long)B * B)), dim3(256), 0, (hipStream_t)stream, Z, lse, lse + B,

@@ -199,6 +199,30 @@ def _grad_into(param: torch.Tensor, writer):
 
 
 # ------------------------------------------------------------------------------------------ raw wrappers
+# Per-shape k-tile policy of the NT products (`tune` of stil_gemm_nt), chosen from tests/tools/gemm_lab.hip's table of the step's
+# shapes and confirmed on the whole step (profiles/r05_experiments.txt): STIL_GEMM_POLICY = "" (the library's automatic choice
+# everywhere) | "k2048:200" style rules "k<minK>:<tune>" applied to products without operand-staging BatchNorm.
+_POLICY = []
+for _r in __import__("os").environ.get("STIL_GEMM_POLICY", "").split(","):
+    if _r.strip():
+        _k, _t = _r.strip().split(":")
+        _POLICY.append((int(_k[1:]), int(_t)))
+_POLICY.sort(reverse=True)
+
+
+def _shape_tune(M, N, K, a_bn, has_bstats):
+    """The `tune` argument of this product: TUNE["gemm"] when forced (measurement tools), else the first policy rule it meets."""
+    t = TUNE["gemm"]
+    if t or a_bn or not _POLICY:
+        return t
+    for mink, tune in _POLICY:
+        if K >= mink:
+            if tune % 100 not in (0, 11) and (has_bstats or M % 128 or N % 128):   # bstats / ragged tiles stay on 64x64
+                return t
+            return tune
+    return t
+
+
 def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None, bias=None, sub=None, scale=None, shift=None,
             resid=None, pre=None, act=0, alpha=1.0, pads=None, outmap=None, out_rows=None, colstats=None, a_bn=None, relu_mask=None,
             bstats=None, scale_var=None, var_eps=0.0):
@@ -218,6 +242,7 @@ def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None,
         out = torch.empty((M if out_rows is None else out_rows, N), dtype=torch.float32, device=A.device)
     L = lib()
     meta = None
+    tune = _shape_tune(M, N, K, a_bn is not None, bstats is not None)
     if L._prof is not None:  # bench bookkeeping: tile variant + ALGORITHMIC flops (strided dgrad gathers count the conv's flops)
         s2 = geom[7] * geom[7] if geom[9] == 1 else 1
         src = (M // (geom[3] * geom[4])) * geom[0] * geom[1] * geom[2]  # gather source (each element fetched once, ideally)
@@ -226,11 +251,11 @@ def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None,
         nbytes = 4.0 * (src + N * K + M * N * (1 + (resid is not None) + (pre is not None) + (relu_mask is not None) + (bstats is not None)))
         plain = int(geom[5] * geom[6] == 1 and geom[7] == 1 and pads == (0, 0) and geom[9] == 0 and outmap[0] == 1
                     and geom[0] == geom[3] and geom[1] == geom[4])
-        cfg = L.gemm_nt_config(_p(A), _p(W), M, N, K, lda, ldb, geom[2], geom[5], geom[6], plain, int(a_bn is not None), TUNE["gemm"])
+        cfg = L.gemm_nt_config(_p(A), _p(W), M, N, K, lda, ldb, geom[2], geom[5], geom[6], plain, int(a_bn is not None), tune)
         meta = (cfg, 2.0 * M * N * K / s2, (M, N, K, geom[5], geom[7], geom[9]), nbytes)
     sw, swn = None, 0
     if _SPLITK:
-        swn = L.gemm_nt_split_workspace_bytes(M, N, K, TUNE["gemm"])
+        swn = L.gemm_nt_split_workspace_bytes(M, N, K, tune)
         if swn:
             sw = _split_ws.get(swn, A.device)
     L.gemm_nt(_p(A), _p(W), _p(out), M, N, K, lda, ldb, ldc, *geom[:8], pads[0], pads[1], geom[9], *outmap,
@@ -238,7 +263,7 @@ def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None,
               (ldc if resid is not None else 0), _p(pre), act, float(alpha), _p(colstats), _p(a_bn), _p(relu_mask),
               (ldc if relu_mask is not None else 0), *((_p(bstats[0]), _p(bstats[1]), _p(bstats[2]), int(bstats[3]), int(bstats[4]))
                                                        if bstats is not None else (None, None, None, 0, 0)),
-              _p(scale_var), float(var_eps), _p(sw), (sw.numel() if sw is not None else 0), TUNE["gemm"], _stream(), meta=meta)
+              _p(scale_var), float(var_eps), _p(sw), (sw.numel() if sw is not None else 0), tune, _stream(), meta=meta)
     return out
 
 
@@ -981,7 +1006,7 @@ class ClipFromLogitsFn(torch.autograd.Function):
     def forward(ctx, Z, lam0):
         _chk(Z)
         B = Z.shape[0]
-        lse = torch.empty((2, B), dtype=torch.float32, device=Z.device)
+        lse = torch.empty((2, B), dtype=torch.float64, device=Z.device)   # row / column log-sum-exps in double (csrc/loss.hip: why)
         terms = torch.empty((B,), dtype=torch.float32, device=Z.device)
         loss = torch.empty((), dtype=torch.float32, device=Z.device)
         lib().clip_fwd(_p(Z), _p(lse), _p(terms), _p(loss), B, lam0, 1.0 - lam0, _stream())

@@ -97,40 +97,27 @@ def _check_flips(flips):
         assert mag <= NORTH_STAR * (1.0 + scale), f"decision {t}: {n} units differ from float64 with |pre-activation| up to {mag:.2e} (tensor max {scale:.2e})"
 
 
-# Tensors whose fp32 yardstick is taken per MODULE (the larger of the weight's and the bias' e32) instead of per tensor: the ITC
-# projection heads only.  Their bias gradient is the column sum of rows that cancel to 7 % of their norm (tests/tools/
-# itc_conditioning.py), so ONE fp32 realisation of it is itself noise -- the reference's own fp32 path lands anywhere in
-# 4.8e-5 .. 6.6e-5 on projector_imaging.bias at the BASELINE shape while the weight of the same head, fed by the same incoming
-# gradient, sits at 1.6e-4 (measured decomposition: DESIGN.md section 2).  Every other tensor keeps the per-tensor bound.
-MODULE_YARDSTICK = ("projector_imaging", "projector_tabular")
-
-
 def _grad_errors(params, g64, e32_of):
     """relative L2 error of every device gradient against the float64 oracle evaluated on the device's own
-    decisions, judged against the reference's own fp32-vs-fp64 distance e32 OF THAT TENSOR: err <= 3 * e32 + 1e-4.
-    For the allow-listed ill-conditioned heads (MODULE_YARDSTICK) e32 is the larger of the module's weight's and bias'; the
-    per-tensor ratio of those tensors is printed beside it so that drift stays visible."""
-    mod = lambda k: k.rsplit(".", 1)[0]
+    decisions, judged against the reference's own fp32-vs-fp64 distance e32 OF THAT TENSOR, one realisation:
+    err <= 3 * e32 + 1e-4 for EVERY tensor.  (Round 4 had widened the yardstick to per-module / two realisations because
+    projector_imaging.bias sat at 2e-4 against ATen's 5e-5; round 5 found the operator -- a log-sum-exp error common to all rows
+    of the CLIP softmax, amplified by the batch size in that one gradient, csrc/loss.hip -- fixed it, and the bound is per tensor
+    again: DESIGN.md section 2.)"""
     e32s = {k: e32_of(k) for k, g in g64.items() if g is not None}
-    e_mod = {}
-    for k, e in e32s.items():
-        e_mod[mod(k)] = max(e_mod.get(mod(k), 0.0), e)
-    bad, ratios, named, listed = [], [], [], []
+    bad, ratios, named = [], [], []
     for k, g in g64.items():
         p = params[k]
         if g is None:
             assert not p._stil_touched, k
             continue
-        e32 = e_mod[mod(k)] if mod(k) in MODULE_YARDSTICK else e32s[k]
+        e32 = e32s[k]
         err = float((p._gslot.cpu().double() - g).norm() / (g.norm() + 1e-30))
         ratios.append(err / (3 * e32 + 1e-4))
-        named.append((ratios[-1], k, f"{err:.2e}", f"e32 {e32s[k]:.2e}"))
-        if mod(k) in MODULE_YARDSTICK:
-            listed.append((k, f"err {err:.2e}", f"per-tensor ratio {err / (3 * e32s[k] + 1e-4):.2f}", f"per-module ratio {ratios[-1]:.2f}"))
+        named.append((ratios[-1], k, f"{err:.2e}", f"e32 {e32:.2e}"))
         if err > 3 * e32 + 1e-4:
             bad.append(("grad " + k, err, e32))
     print("closest to their bound:", sorted(named, reverse=True)[:4])
-    print("per-module yardstick (ITC heads):", listed)
     return bad, ratios
 
 
@@ -411,23 +398,15 @@ def test_baseline_shape_step_matches_oracle():
             ok, err = _close(msd[k].cpu().double().numpy(), v.double().numpy(), 5e-5)
             if not ok:
                 bad.append(("state " + k, err))
-    # gradients: float64 on the device's decisions; yardstick = the CPU fp32 oracle on the same decisions
-    # The yardstick is the fp32 noise level of each tensor: TWO fp32 evaluations on the same decisions -- the oracle as it is, and
-    # the oracle from weights perturbed by one ulp (seeded) -- and the larger of their distances from float64.  One realisation
-    # alone is itself noise: for the ill-conditioned ITC heads (batch sums of nearly cancelling rows) it scatters between 4e-5 and
-    # 2e-4 from case to case while the device sits at 1.2-2.5e-4 on all of them (round 4: `projector_imaging.bias` here, 2.0e-4
-    # against a single-realisation 3.7e-5).
+    # gradients: float64 on the device's decisions; yardstick = the CPU fp32 oracle on the same decisions, per tensor
     with O.force_decisions(*decisions):
         o32 = O.full_step({k: v.clone() for k, v in sd0.items()}, {}, 1, batch, hp, 1, mr, mm)
-        gp = torch.Generator().manual_seed(77)
-        sd_p = {k: (v * (1 + 6e-8 * (torch.rand(v.shape, generator=gp) * 2 - 1)) if (v.is_floating_point() and k in tr) else v.clone()) for k, v in sd0.items()}
-        o32b = O.full_step(sd_p, {}, 1, batch, hp, 1, mr, mm)
     flips = {t: v for t, v in o64["flips"].items() if v[0]}
     _check_flips(flips)
 
     def e32_of(k):
         g64 = o64["grads"][k]
-        return max(float((o_["grads"][k].double() - g64).norm() / (g64.norm() + 1e-30)) for o_ in (o32, o32b))
+        return float((o32["grads"][k].double() - g64).norm() / (g64.norm() + 1e-30))
 
     gbad, ratios = _grad_errors(_named_params(m), o64["grads"], e32_of)
     bad += gbad
@@ -550,7 +529,7 @@ def test_configs1_full_size_backward_matches_oracle():
     paths B = 32 never does (weight-gradient M-splits, > 256-tile BatchNorm finalisation in two launches, more XCD-remapped
     tiles).  One device step (decisions exported), one fp32 oracle.full_step on the device's ReLU / max-pool decisions (about two
     minutes on the box's 16 cores), then: EVERY gradient tensor relL2(device, fp32 oracle) <= 4 e32 + 1e-4, where e32 is the
-    REFERENCE's own fp32-vs-float64 distance of that tensor at this architecture (fixture dvm_r50_b32_224, per module) -- the
+    REFERENCE's own fp32-vs-float64 distance of that tensor at this architecture (fixture dvm_r50_b32_224) -- the
     B = 32 test's bar (3 e32 + 1e-4 against float64) plus the fp32 oracle's own e32; BatchNorm running statistics, the EMA
     teacher and the prototype accumulators at 5e-5; |delta Adam| <= 2.2 lr."""
     from stil_tta_amd.driver import train_step
@@ -579,17 +558,12 @@ def test_configs1_full_size_backward_matches_oracle():
     cs = flags[:, 0]
     assert torch.equal(cs == 1, o["case1"]) and torch.equal(cs == 2, o["case2_i"]) and torch.equal(cs == 3, o["case2_t"]) and torch.equal(cs == 4, o["case3"])
     assert torch.equal(flags[:, 1].bool(), o["mask1"])
-    mod = lambda k: k.rsplit(".", 1)[0]
-    e_mod = {}
-    for k in o["grads"]:
-        if "gerr32_" + k in fx.files:
-            e_mod[mod(k)] = max(e_mod.get(mod(k), 0.0), float(fx["gerr32_" + k]))
     bad, named = [], []
     for k, g in o["grads"].items():
         if g is None:
             assert not touched[k], k
             continue
-        e32 = e_mod[mod(k)]
+        e32 = float(fx["gerr32_" + k])
         err = float((gdev[k] - g.double()).norm() / (g.double().norm() + 1e-30))
         named.append((err / (4 * e32 + 1e-4), k, f"{err:.2e}", f"e32 {e32:.2e}"))
         if err > 4 * e32 + 1e-4:

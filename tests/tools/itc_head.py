@@ -27,7 +27,7 @@ def head_grads(sd, x_ai, x_at, T, lam0, dtype):
 
 
 def rel(a, b):
-    a, b = a.double(), b.double()
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
