@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=32, help="batch of the CPU baseline (BASELINE.md section 3: 32; 256 = the bench's own batch, ~2 min per step)")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps after one warm-up (BASELINE.md section 3: >= 3)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (driver.GraphedTrainStep)")
+    ap.add_argument("--launch", choices=["auto", "eager", "graph"], default="auto",
+                    help="auto: hipGraph replay when the per-GPU step is launch-bound (driver.wants_graph: batch x pixels), eager otherwise; "
+                         "--graph = --launch graph")
     ap.add_argument("--host-input", action="store_true", help="every step's batch starts in pageable host memory and goes through "
                     "data.DevicePrefetcher (PCIe-inclusive rate; NOT the contract's `value`, which has inputs resident in HBM)")
     ap.add_argument("--breakdown", action="store_true", help="also print per-entry-point GPU time of the last step (stderr)")
@@ -348,6 +351,9 @@ def main():
         views = [(imu, tabu), (imu.flip(3).contiguous(), tabu)] + ([(imu.flip(2).contiguous(), tabu)] if a.variant == "comatch" else [])
         batch = {"l": ((iml, tabl), yl, torch.arange(len(yl), device=dev)), "u": (views, yu)}
 
+    from stil_tta_amd.driver import wants_graph
+    a.graph = a.graph or a.launch == "graph" or (a.launch == "auto" and world == 1 and a.variant in ("dvm", "saint", "cardiac") and not a.host_input
+                                                 and a.pipeline == "resident" and wants_graph(a.batch, a.img))
     if a.graph:
         from stil_tta_amd.driver import GraphedTrainStep
         gstep = GraphedTrainStep(m, opt, batch, warmup=max(1, a.warmup))

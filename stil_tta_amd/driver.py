@@ -183,6 +183,14 @@ def synthetic_batch(field_lengths, num_classes: int, B: int, img_size: int, seed
     return {"l": part(slice(0, B_l), True), "u": part(slice(B_l, B), False)}
 
 
+def wants_graph(batch: int, img_size: int) -> bool:
+    """Is a step of this per-GPU size bound by its ~1100 dependent launches rather than by the chip?  Measured (profiles/r04z_*,
+    r05_*): the cardiac share of 16 samples per GPU at 128 px runs 21.5-23.5 ms eager and 13.6-15.8 ms replayed; B = 64 at 128 px
+    and B = 32 at 224 px are equal either way; from there on eager launches win (B = 256: 130 vs 138 ms).  The boundary is put at
+    half a million pixels per step."""
+    return batch * img_size * img_size <= 524288
+
+
 class GraphedTrainStep:
     """The whole optimisation step (zero_grad -> training_step -> backward -> all-reduce -> Adam) captured ONCE into a
     hipGraph and replayed: ~1500 kernel launches per step collapse into one graph launch, which is what matters when

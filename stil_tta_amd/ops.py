@@ -74,12 +74,13 @@ class _SplitWorkspace(_Workspace):
 
 
 _split_ws = _SplitWorkspace()
-# Split-K of the NT products whose grid is below one workgroup per CU (include/stil_hip.h `split_ws`): OPT-IN (STIL_SPLITK=1, or
-# ops._SPLITK = True) -- it pays only for small per-GPU batches (cardiac share of 16 samples per GPU: 16.6 -> 13.8 ms per step under
-# graph replay; nothing at B = 256, profiles/r04_experiments.txt), and it re-rolls the rounding of every small product of the step,
-# which moves the one ill-conditioned gradient of the BASELINE-shape parity test (projector_imaging.bias: 0.97 of its bound
-# without, 1.03 with) across its bar.
-_SPLITK = __import__("os").environ.get("STIL_SPLITK", "0") != "0"
+# Split-K of the NT products whose grid is below one workgroup per CU (include/stil_hip.h `split_ws`): AUTOMATIC -- the library
+# splits only products of fewer than 256 tiles with K >= 256 (gemm.hip nt_splits), i.e. what a per-GPU batch of 16-64 samples
+# launches (cardiac share of 16 samples per GPU: 16.6 -> 13.8 ms per step under graph replay) and, at B = 256, only the heads'
+# M = 256 products (step unchanged: 2117.0 / 2116.4 samples/s, profiles/r04_experiments.txt 9).  Round 4 kept it opt-in because it
+# re-rolls the rounding of every small product, which moved projector_imaging.bias across its bar; that gradient's noise had
+# another cause (csrc/loss.hip, round 5) and sits at 0.1-0.4 of its bar now.  STIL_SPLITK=0 turns it off.
+_SPLITK = __import__("os").environ.get("STIL_SPLITK", "1") != "0"
 
 # per-call tuning arguments of stil_gemm_nt / stil_wgrad_tn (include/stil_hip.h); 0 = automatic.  Only the measurement
 # tools and bench.py's A/B environment knobs (STIL_GEMM_TUNE, STIL_WGRAD_TUNE) set them.
@@ -210,14 +211,14 @@ for _r in __import__("os").environ.get("STIL_GEMM_POLICY", "").split(","):
 _POLICY.sort(reverse=True)
 
 
-def _shape_tune(M, N, K, a_bn, has_bstats):
+def _shape_tune(M, N, K, a_bn, has_tile_stats):
     """The `tune` argument of this product: TUNE["gemm"] when forced (measurement tools), else the first policy rule it meets."""
     t = TUNE["gemm"]
     if t or a_bn or not _POLICY:
         return t
     for mink, tune in _POLICY:
         if K >= mink:
-            if tune % 100 not in (0, 11) and (has_bstats or M % 128 or N % 128):   # bstats / ragged tiles stay on 64x64
+            if tune % 100 not in (0, 11) and (has_tile_stats or M % 128 or N % 128):   # per-tile statistics (64-row tiles) / ragged tiles stay on 64x64
                 return t
             return tune
     return t
@@ -242,7 +243,7 @@ def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None,
         out = torch.empty((M if out_rows is None else out_rows, N), dtype=torch.float32, device=A.device)
     L = lib()
     meta = None
-    tune = _shape_tune(M, N, K, a_bn is not None, bstats is not None)
+    tune = _shape_tune(M, N, K, a_bn is not None, bstats is not None or colstats is not None)
     if L._prof is not None:  # bench bookkeeping: tile variant + ALGORITHMIC flops (strided dgrad gathers count the conv's flops)
         s2 = geom[7] * geom[7] if geom[9] == 1 else 1
         src = (M // (geom[3] * geom[4])) * geom[0] * geom[1] * geom[2]  # gather source (each element fetched once, ideally)

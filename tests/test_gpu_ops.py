@@ -907,6 +907,8 @@ def test_gemm_split_k_is_the_unsplit_product_and_deterministic(ops, M, N, K, con
         A, geom = dev(torch.randn(M, K, generator=g)), None
     nt = (M + 63) // 64
 
+    default_split = ops._SPLITK
+
     def run(split):
         ops._SPLITK = split
         try:
@@ -916,7 +918,7 @@ def test_gemm_split_k_is_the_unsplit_product_and_deterministic(ops, M, N, K, con
             torch.cuda.synchronize()
             return raw, out, ts
         finally:
-            ops._SPLITK = False
+            ops._SPLITK = default_split
     ref = run(False)
     got = [run(True) for _ in range(3)]
     ops._SPLITK = True       # (restored at the end of the test)
@@ -946,4 +948,4 @@ def test_gemm_split_k_is_the_unsplit_product_and_deterministic(ops, M, N, K, con
         assert torch.equal(outs["a"], got[0][1]), "split-K result changed when another stream ran a split product beside it"
         close(outs["b"], ops.gemm_nt(A2, W, M, N, K, geom=geom, bias=b, resid=R, act=1), tol=0.0, name="second stream")
     finally:
-        ops._SPLITK = False
+        ops._SPLITK = default_split

@@ -1,0 +1,235 @@
+// Pricing of the split-precision GEMM (SURVEY section 7's opt-in perf mode; round-4 verdict item 4) on gfx950 -- measurement tool.
+// An fp32 operand is split into three bf16 terms a = a1 + a2 + a3 (a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2): 24
+// mantissa bits in all) and the product is formed from the six term pairs of weight >= 2^-16 on v_mfma_f32_32x32x16_bf16
+// (fp32 accumulate): 6 x 32 cycles per 32x32x16 block against 8 x 64 cycles of v_mfma_f32_32x32x2_f32 -- a 2.67x higher ceiling.
+//   P: operands pre-split into bf16 planes in HBM (6 bytes per element instead of 4), 128x128 tile, 4 waves of 2x2 MFMA tiles
+//   F: fp32 operands split on the fly while they are staged into LDS (what a drop-in for stil_gemm_nt would do)
+// against the fp32-exact 64x64 kernel of tests/tools/gemm_lab.hip, on the step's shapes, with the relative L2 error of each against
+// a float64 product.        build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tests/tools/bf16x3_lab tests/tools/bf16x3_lab.hip
+#define GEMM_LAB_NO_MAIN
+#include "gemm_lab.hip"
+#include <math.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+struct Args3 {
+  const u16* A3; const u16* W3;   // P: [3][M][K], [3][N][K] bf16 planes
+  const float* A; const float* W; // F: fp32 operands
+  float* C;
+  int M, N, K;
+};
+
+__device__ __forceinline__ void split3(float a, __bf16& a1, __bf16& a2, __bf16& a3) {
+  a1 = (__bf16)a;
+  const float r1 = a - (float)a1;      // exact
+  a2 = (__bf16)r1;
+  const float r2 = r1 - (float)a2;     // exact
+  a3 = (__bf16)r2;
+}
+
+__global__ void split_planes_kernel(const float* __restrict__ x, u16* __restrict__ p, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    __bf16 a1, a2, a3;
+    split3(x[i], a1, a2, a3);
+    p[i] = *reinterpret_cast<u16*>(&a1); p[n + i] = *reinterpret_cast<u16*>(&a2); p[2 * n + i] = *reinterpret_cast<u16*>(&a3);
+  }
+}
+
+// 128x128 block tile, 256 threads = 2x2 waves x (2x2 tiles of 32x32), BK = 32, one LDS buffer: [operand][plane][128 rows][40 bf16]
+template <bool FLY>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void bf16x3_kernel(Args3 p) {
+  constexpr int LS = 40;                       // bf16 per LDS row: 64 B of data + 16 B pad (conflict-free ds_read_b128)
+  constexpr int PL = 128 * LS;                 // one plane of one operand
+  extern __shared__ __attribute__((aligned(16))) float lds_f[];
+  __bf16* lds = reinterpret_cast<__bf16*>(lds_f);
+  const int nbn = p.N / 128, nbm = p.M / 128;
+  const int wg = xcd_remap(blockIdx.x, nbm * nbn);
+  const int tm = wg / nbn, tn = wg - tm * nbn;
+  const int tid = threadIdx.x, w = tid >> 6, wm = w >> 1, wn = w & 1, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  f32x4 st[FLY ? 8 : 12];                      // staged global loads of the next k-tile
+  const long Mk = (long)p.M * p.K, Nk = (long)p.N * p.K;
+  int k0 = 0;
+  auto load = [&]() __attribute__((always_inline)) {
+    if constexpr (FLY) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i, row = c >> 3, q = c & 7;
+        st[i] = *reinterpret_cast<const f32x4*>(p.A + (long)(tm * 128 + row) * p.K + k0 + q * 4);
+        st[4 + i] = *reinterpret_cast<const f32x4*>(p.W + (long)(tn * 128 + row) * p.K + k0 + q * 4);
+      }
+    } else {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int c = tid + 256 * i, row = c >> 2, q = c & 3;
+          st[pl * 2 + i] = *reinterpret_cast<const f32x4*>(p.A3 + pl * Mk + (long)(tm * 128 + row) * p.K + k0 + q * 8);
+          st[6 + pl * 2 + i] = *reinterpret_cast<const f32x4*>(p.W3 + pl * Nk + (long)(tn * 128 + row) * p.K + k0 + q * 8);
+        }
+    }
+    k0 += 32;
+  };
+  auto lstore = [&]() __attribute__((always_inline)) {
+    if constexpr (FLY) {
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int c = tid + 256 * i, row = c >> 3, q = c & 7;
+          bf16x4 h1, h2, h3;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { __bf16 a1, a2, a3; split3(st[o * 4 + i][e], a1, a2, a3); h1[e] = a1; h2[e] = a2; h3[e] = a3; }
+          __bf16* dst = lds + o * 3 * PL + row * LS + q * 4;
+          *reinterpret_cast<bf16x4*>(dst) = h1; *reinterpret_cast<bf16x4*>(dst + PL) = h2; *reinterpret_cast<bf16x4*>(dst + 2 * PL) = h3;
+        }
+    } else {
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i, row = c >> 2, q = c & 3;
+            *reinterpret_cast<f32x4*>(lds + (o * 3 + pl) * PL + row * LS + q * 8) = st[o * 6 + pl * 2 + i];
+          }
+    }
+  };
+  const int nk = p.K / 32;
+  load();
+  lstore();
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 a[3][2], b[3][2];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          a[pl][i] = *reinterpret_cast<const bf16x8*>(lds + pl * PL + (wm * 64 + i * 32 + li) * LS + s * 16 + lh * 8);
+          b[pl][i] = *reinterpret_cast<const bf16x8*>(lds + (3 + pl) * PL + (wn * 64 + i * 32 + li) * LS + s * 16 + lh * 8);
+        }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {   // smallest terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+        }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    __syncthreads();
+    if (kt + 1 < nk) lstore();
+    __syncthreads();
+  }
+  Args q{nullptr, nullptr, p.C, p.M, p.N, p.K, 0, 0, nullptr, nullptr, nullptr};
+  Tile<2, 2, 32, 1>::store(q, lds_f, tm, tn, acc);
+}
+
+int main(int argc, char** argv) {
+  const int rounds = argc > 1 ? atoi(argv[1]) : 4;
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  g_cus = prop.multiProcessorCount;
+  std::vector<Shape> shapes = {
+      {50176, 256, 2304, "layer3 3x3 (as plain K)"}, {12544, 512, 4608, "layer4 3x3 (as plain K)"}, {200704, 128, 1152, "layer2 3x3 (as plain K)"},
+      {50176, 256, 1024, "layer3 conv1"}, {50176, 1024, 256, "layer3 conv3"}, {12544, 512, 2048, "layer4 conv1"}, {12544, 2048, 512, "layer4 conv3"},
+      {16640, 512, 2048, "tab fc2"}, {16640, 2048, 512, "tab fc1"}, {200704, 128, 512, "layer2 conv1"}, {200704, 512, 128, "layer2 conv3"},
+      {802816, 256, 64, "layer1 conv3"}};
+  const int SETS = 3;
+  size_t maxA = 0, maxW = 0, maxC = 0;
+  for (auto& s : shapes) { maxA = std::max(maxA, (size_t)s.M * s.K); maxW = std::max(maxW, (size_t)s.N * s.K); maxC = std::max(maxC, (size_t)s.M * s.N); }
+  float *A[SETS], *W[SETS], *C[SETS];
+  u16 *A3[SETS], *W3[SETS];
+  std::vector<float> hA(maxA), hW(maxW);
+  {
+    unsigned s = 12345u;
+    for (auto& v : hA) { s = s * 1664525u + 1013904223u; v = ((int)(s >> 8) % 20001 - 10000) * 1e-4f * (1.f + (s & 255) * 1e-3f); }
+    for (auto& v : hW) { s = s * 1664525u + 1013904223u; v = ((int)(s >> 8) % 20001 - 10000) * 1e-4f * (1.f + (s & 255) * 1e-3f); }
+  }
+  for (int i = 0; i < SETS; ++i) {
+    CK(hipMalloc(&A[i], maxA * 4)); CK(hipMalloc(&W[i], maxW * 4)); CK(hipMalloc(&C[i], maxC * 4));
+    CK(hipMalloc(&A3[i], maxA * 6)); CK(hipMalloc(&W3[i], maxW * 6));
+    CK(hipMemcpy(A[i], hA.data(), maxA * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(W[i], hW.data(), maxW * 4, hipMemcpyHostToDevice));
+  }
+  CK(hipFuncSetAttribute((const void*)bf16x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  CK(hipFuncSetAttribute((const void*)bf16x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  const size_t lds3 = (size_t)6 * 128 * 40 * 2;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  {   // warm the chip up
+    Args p{A[0], W[0], C[0], 50176, 256, 2304, 0, 0, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 600; ++i) launch_tile<1, 1, 32, 1, 4>(p, 0);
+    CK(hipDeviceSynchronize());
+  }
+  printf("%-28s %10s %10s %10s %10s | relL2 vs float64: %9s %9s %9s\n", "shape", "fp32 MFMA", "bf16x3 P", "bf16x3 F", "split pass", "fp32 MFMA", "bf16x3 P", "bf16x3 F");
+  for (auto& sh : shapes) {
+    const size_t nA = (size_t)sh.M * sh.K, nW = (size_t)sh.N * sh.K, nC = (size_t)sh.M * sh.N;
+    for (int i = 0; i < SETS; ++i) {   // planes of THIS shape's operands (the operands are the leading nA / nW floats of the buffers)
+      hipLaunchKernelGGL(split_planes_kernel, dim3(4096), dim3(256), 0, 0, A[i], A3[i], (long)nA);
+      hipLaunchKernelGGL(split_planes_kernel, dim3(4096), dim3(256), 0, 0, W[i], W3[i], (long)nW);
+    }
+    CK(hipDeviceSynchronize());
+    // float64 reference of the first 64 rows
+    const int RR = 64;
+    std::vector<double> ref((size_t)RR * sh.N);
+    for (int r = 0; r < RR; ++r)
+      for (int n = 0; n < sh.N; ++n) {
+        double s = 0.0;
+        const float* a = hA.data() + (size_t)r * sh.K; const float* w_ = hW.data() + (size_t)n * sh.K;
+        for (int k = 0; k < sh.K; ++k) s += (double)a[k] * (double)w_[k];
+        ref[(size_t)r * sh.N + n] = s;
+      }
+    auto launch = [&](int v, int set) {
+      if (v == 0) { Args p{A[set], W[set], C[set], sh.M, sh.N, sh.K, 0, 0, nullptr, nullptr, nullptr}; launch_tile<1, 1, 32, 1, 4>(p, 0); }
+      else {
+        Args3 p{A3[set], W3[set], A[set], W[set], C[set], sh.M, sh.N, sh.K};
+        if (v == 1) hipLaunchKernelGGL((bf16x3_kernel<false>), dim3((sh.M / 128) * (sh.N / 128)), dim3(256), lds3, 0, p);
+        else hipLaunchKernelGGL((bf16x3_kernel<true>), dim3((sh.M / 128) * (sh.N / 128)), dim3(256), lds3, 0, p);
+      }
+    };
+    double best[4] = {1e30, 1e30, 1e30, 1e30}, err[3] = {0, 0, 0};
+    std::vector<float> out((size_t)RR * sh.N);
+    for (int v = 0; v < 3; ++v) {
+      CK(hipMemsetAsync(C[0], 0xff, nC * 4, 0));
+      launch(v, 0);
+      CK(hipDeviceSynchronize()); CK(hipGetLastError());
+      CK(hipMemcpy(out.data(), C[0], out.size() * 4, hipMemcpyDeviceToHost));
+      double num = 0, den = 0;
+      for (size_t i = 0; i < out.size(); ++i) { const double d = (double)out[i] - ref[i]; num += d * d; den += ref[i] * ref[i]; }
+      err[v] = sqrt(num / den);
+    }
+    for (int r = 0; r < rounds; ++r)
+      for (int v = 0; v < 4; ++v) {
+        CK(hipEventRecord(e0, 0));
+        for (int it = 0; it < 6; ++it) {
+          const int set = (it + r) % SETS;
+          if (v < 3) launch(v, set);
+          else { hipLaunchKernelGGL(split_planes_kernel, dim3(4096), dim3(256), 0, 0, A[set], A3[set], (long)nA); }
+        }
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        best[v] = std::min(best[v], (double)ms / 6);
+      }
+    const double fl = 2.0 * sh.M * sh.N * sh.K;
+    char nm[64]; snprintf(nm, sizeof nm, "(%d, %d, %d)", sh.M, sh.N, sh.K);
+    printf("%-28s %7.1f TF %7.1f TF %7.1f TF %7.0f us | %27.2e %9.2e %9.2e\n", nm, fl / best[0] * 1e-9, fl / best[1] * 1e-9, fl / best[2] * 1e-9, best[3] * 1e3,
+           err[0], err[1], err[2]);
+    fflush(stdout);
+  }
+  return 0;
+}

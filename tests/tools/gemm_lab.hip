@@ -292,6 +292,7 @@ static bool launch_streamk(const Args& p0, hipStream_t s) {
   return true;
 }
 
+#ifndef GEMM_LAB_NO_MAIN
 int main(int argc, char** argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 5;
   const char* only = argc > 2 ? argv[2] : nullptr;
@@ -396,3 +397,4 @@ int main(int argc, char** argv) {
   }
   return 0;
 }
+#endif
