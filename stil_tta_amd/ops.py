@@ -281,11 +281,16 @@ def wgrad_tn(dY, X, dW, M, N, K, *, ldy=None, ldx=None, geom=None, Kdst=None, ac
     L.wgrad_tn(_p(dY), _p(X), _p(dW), M, N, K, ldy, ldx, *geom, Kdst, accumulate, _p(x_bn), _p(w), nb, TUNE["wgrad"], _stream(), meta=meta)
 
 
+# STIL_WGRAD_SIDE=0: weight gradients stay on the main stream while the EMA teacher keeps the side stream (A/B measurements of the
+# two-stream structure: does co-running two MFMA-bound kernels pay? profiles/r05_experiments.txt)
+_WGRAD_SIDE = __import__("os").environ.get("STIL_WGRAD_SIDE", "1") != "0"
+
+
 def wgrad_param(param, dY, X, M, N, K, **kw):
     """Weight gradient of a parameter.  Slab-backed parameters: "+=" into the slot on the side stream (returns None);
     plain tensors: fresh gradient on the current stream (returned to autograd)."""
     slot = getattr(param, "_gslot", None)
-    side = side_stream(dY.device) if slot is not None else None
+    side = side_stream(dY.device) if (slot is not None and _WGRAD_SIDE) else None
     if side is None:
         return _grad_into(param, lambda dst, acc: wgrad_tn(dY, X, dst, M, N, K, accumulate=acc, **kw))
     main = torch.cuda.current_stream()

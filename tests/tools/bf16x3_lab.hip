@@ -38,7 +38,8 @@ __global__ void split_planes_kernel(const float* __restrict__ x, u16* __restrict
 }
 
 // 128x128 block tile, 256 threads = 2x2 waves x (2x2 tiles of 32x32), BK = 32, one LDS buffer: [operand][plane][128 rows][40 bf16]
-template <bool FLY>
+// ACC2: two-level accumulation as in the fp32 kernels (chains of 64 k into a partial accumulator, then into the master)
+template <bool FLY, bool ACC2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void bf16x3_kernel(Args3 p) {
   constexpr int LS = 40;                       // bf16 per LDS row: 64 B of data + 16 B pad (conflict-free ds_read_b128)
   constexpr int PL = 128 * LS;                 // one plane of one operand
@@ -107,8 +108,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
   load();
   lstore();
   __syncthreads();
+  f32x16 part[2][2];
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) load();
+    if (ACC2 && (kt & 1) == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) part[i][j][r] = 0.f;
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 a[3][2], b[3][2];
@@ -124,14 +134,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {   // smallest terms first
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+          f32x16& c = ACC2 ? part[i][j] : acc[i][j];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);
         }
       __builtin_amdgcn_s_setprio(0);
+    }
+    if (ACC2 && ((kt & 1) == 1 || kt + 1 == nk)) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] += part[i][j];
     }
     __syncthreads();
     if (kt + 1 < nk) lstore();
@@ -167,8 +184,9 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&A3[i], maxA * 6)); CK(hipMalloc(&W3[i], maxW * 6));
     CK(hipMemcpy(A[i], hA.data(), maxA * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(W[i], hW.data(), maxW * 4, hipMemcpyHostToDevice));
   }
-  CK(hipFuncSetAttribute((const void*)bf16x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-  CK(hipFuncSetAttribute((const void*)bf16x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  CK(hipFuncSetAttribute((const void*)bf16x3_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  CK(hipFuncSetAttribute((const void*)bf16x3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  CK(hipFuncSetAttribute((const void*)bf16x3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   const size_t lds3 = (size_t)6 * 128 * 40 * 2;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   {   // warm the chip up
@@ -176,7 +194,8 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 600; ++i) launch_tile<1, 1, 32, 1, 4>(p, 0);
     CK(hipDeviceSynchronize());
   }
-  printf("%-28s %10s %10s %10s %10s | relL2 vs float64: %9s %9s %9s\n", "shape", "fp32 MFMA", "bf16x3 P", "bf16x3 F", "split pass", "fp32 MFMA", "bf16x3 P", "bf16x3 F");
+  printf("P = pre-split bf16 planes, F = split on the fly; two-level sums (chains of 64) unless '1-level'\n");
+  printf("%-24s %10s %10s %10s %11s %10s | relL2 vs float64: %9s %9s %9s %9s\n", "shape", "fp32 MFMA", "bf16x3 P", "bf16x3 F", "P 1-level", "split pass", "fp32 MFMA", "bf16x3 P", "bf16x3 F", "P 1-level");
   for (auto& sh : shapes) {
     const size_t nA = (size_t)sh.M * sh.K, nW = (size_t)sh.N * sh.K, nC = (size_t)sh.M * sh.N;
     for (int i = 0; i < SETS; ++i) {   // planes of THIS shape's operands (the operands are the leading nA / nW floats of the buffers)
@@ -198,13 +217,14 @@ int main(int argc, char** argv) {
       if (v == 0) { Args p{A[set], W[set], C[set], sh.M, sh.N, sh.K, 0, 0, nullptr, nullptr, nullptr}; launch_tile<1, 1, 32, 1, 4>(p, 0); }
       else {
         Args3 p{A3[set], W3[set], A[set], W[set], C[set], sh.M, sh.N, sh.K};
-        if (v == 1) hipLaunchKernelGGL((bf16x3_kernel<false>), dim3((sh.M / 128) * (sh.N / 128)), dim3(256), lds3, 0, p);
-        else hipLaunchKernelGGL((bf16x3_kernel<true>), dim3((sh.M / 128) * (sh.N / 128)), dim3(256), lds3, 0, p);
+        if (v == 1) hipLaunchKernelGGL((bf16x3_kernel<false, true>), dim3((sh.M / 128) * (sh.N / 128)), dim3(256), lds3, 0, p);
+        else if (v == 2) hipLaunchKernelGGL((bf16x3_kernel<true, true>), dim3((sh.M / 128) * (sh.N / 128)), dim3(256), lds3, 0, p);
+        else hipLaunchKernelGGL((bf16x3_kernel<false, false>), dim3((sh.M / 128) * (sh.N / 128)), dim3(256), lds3, 0, p);
       }
     };
-    double best[4] = {1e30, 1e30, 1e30, 1e30}, err[3] = {0, 0, 0};
+    double best[5] = {1e30, 1e30, 1e30, 1e30, 1e30}, err[4] = {0, 0, 0, 0};
     std::vector<float> out((size_t)RR * sh.N);
-    for (int v = 0; v < 3; ++v) {
+    for (int v = 0; v < 4; ++v) {
       CK(hipMemsetAsync(C[0], 0xff, nC * 4, 0));
       launch(v, 0);
       CK(hipDeviceSynchronize()); CK(hipGetLastError());
@@ -214,11 +234,11 @@ int main(int argc, char** argv) {
       err[v] = sqrt(num / den);
     }
     for (int r = 0; r < rounds; ++r)
-      for (int v = 0; v < 4; ++v) {
+      for (int v = 0; v < 5; ++v) {
         CK(hipEventRecord(e0, 0));
         for (int it = 0; it < 6; ++it) {
           const int set = (it + r) % SETS;
-          if (v < 3) launch(v, set);
+          if (v < 4) launch(v, set);
           else { hipLaunchKernelGGL(split_planes_kernel, dim3(4096), dim3(256), 0, 0, A[set], A3[set], (long)nA); }
         }
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
@@ -227,8 +247,8 @@ int main(int argc, char** argv) {
       }
     const double fl = 2.0 * sh.M * sh.N * sh.K;
     char nm[64]; snprintf(nm, sizeof nm, "(%d, %d, %d)", sh.M, sh.N, sh.K);
-    printf("%-28s %7.1f TF %7.1f TF %7.1f TF %7.0f us | %27.2e %9.2e %9.2e\n", nm, fl / best[0] * 1e-9, fl / best[1] * 1e-9, fl / best[2] * 1e-9, best[3] * 1e3,
-           err[0], err[1], err[2]);
+    printf("%-24s %7.1f TF %7.1f TF %7.1f TF %8.1f TF %7.0f us | %27.2e %9.2e %9.2e %9.2e\n", nm, fl / best[0] * 1e-9, fl / best[1] * 1e-9, fl / best[2] * 1e-9,
+           fl / best[3] * 1e-9, best[4] * 1e3, err[0], err[1], err[2], err[3]);
     fflush(stdout);
   }
   return 0;

@@ -314,6 +314,9 @@ int main(int argc, char** argv) {
       {"128x64 bk16 nb2", launch_tile<2, 1, 16, 2, 3>},
       {"64x128 bk16 nb2", launch_tile<1, 2, 16, 2, 3>},
       {"64x64 bk16 nb2", launch_tile<1, 1, 16, 2, 4>},
+      {"64x128 bk32 nb1", launch_tile<1, 2, 32, 1, 3>},
+      {"64x256 bk32 nb1 (A once)", launch_tile<1, 4, 32, 1, 2>},
+      {"64x256 bk16 nb2 (A once)", launch_tile<1, 4, 16, 2, 2>},
       {"128x128 bk32 nb1 streamK occ2", launch_streamk<2, 2, 32, 1, 2, 2>},
       {"128x128 bk16 nb2 streamK occ2", launch_streamk<2, 2, 16, 2, 2, 2>},
       {"128x64 bk32 nb1 streamK occ3", launch_streamk<2, 1, 32, 1, 3, 3>},
