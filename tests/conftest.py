@@ -35,6 +35,7 @@ _FILE_ORDER = ["test_gpu_step", "test_gpu_ops", "test_gpu_mmatch", "test_gpu_mat
 _STEP_ORDER = ["test_training_step_matches_reference_golden", "test_configs1_full_size_forward_matches_oracle",
                "test_configs1_full_size_backward_matches_oracle", "test_baseline_shape_step_matches_oracle",
                "test_configs3_saint_bench_shape_forward_matches_oracle", "test_configs4_cardiac_bench_shape_forward_matches_oracle",
+               "test_configs4_cardiac_bench_shape_backward_matches_oracle",
                "test_bench_shape_properties", "test_two_steps_match_oracle_dvm_native_shape", "test_five_step_trajectory_matches_oracle"]
 _MULTI_PROCESS = ("test_two_rank", "test_rccl_", "test_bench_gpus", "two_rank", "_ranks_")
 

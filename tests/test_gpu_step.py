@@ -612,6 +612,50 @@ def test_configs4_cardiac_bench_shape_forward_matches_oracle(B):
     _forward_vs_oracle(f"configs[4] cardiac, B={B}", *_full_size_case(f"configs4_b{B}", CONFIGS4, B, (51 + B, 52, 53, 8), min_cases=2, min_gap=1e-4))
 
 
+@pytest.mark.parametrize("B", [64, 16])
+def test_configs4_cardiac_bench_shape_backward_matches_oracle(B):
+    """configs[4] at its bench shapes, the WHOLE optimisation step (backward + Adam): 128 px, 26 + 49 columns, K = 2, SimCLR heads,
+    B = 64 and the 16-sample share of one GPU -- the regime where the small NT products run split over K (automatic since round 5)
+    and the step is launch-bound.  Same protocol as the BASELINE-shape test: every gradient tensor against the float64 oracle on
+    the device's decisions, yardstick = the fp32 oracle's own distance from float64 on the same decisions, per tensor
+    (err <= 3 e32 + 1e-4); BatchNorm statistics / EMA teacher / prototype sums at 5e-5; |delta Adam| <= 2.2 lr."""
+    from stil_tta_amd.driver import train_step
+    from stil_tta_amd.flat import StilAdam
+    hp, sd0, batch, mr, mm, o_fwd = _full_size_case(f"configs4_b{B}", CONFIGS4, B, (51 + B, 52, 53, 8), min_cases=2, min_gap=1e-4)
+    m = _make_model(hp, {k: v.clone() for k, v in sd0.items()})
+    m.current_epoch = 1
+    with _trace_decisions() as trace:
+        train_step(m, StilAdam(m.flat, lr=hp.lr_eval), _to_dev(batch), mask_random=mr, mi_masks=mm)
+        torch.cuda.synchronize()
+        decisions = _device_decisions(m, trace)
+    o64 = run_oracle64(hp, sd0, batch, 1, mr, mm, decisions=decisions)
+    sd = {k: v.clone() for k, v in sd0.items()}
+    with O.force_decisions(*decisions):
+        o32 = O.full_step(sd, {}, 1, batch, hp, 1, mr, mm)
+    flips = {t: v for t, v in o64["flips"].items() if v[0]}
+    _check_flips(flips)
+    _check_flags(m.last, o32, len(batch["u"][2]))
+
+    def e32_of(k):
+        g64 = o64["grads"][k]
+        return float((o32["grads"][k].double() - g64).norm() / (g64.norm() + 1e-30))
+
+    bad, ratios = _grad_errors(_named_params(m), o64["grads"], e32_of)
+    msd = m.state_dict()
+    tr = set(O.trainable_keys(sd))
+    for k, v in sd.items():
+        if k in tr:
+            if float((msd[k].cpu() - v).abs().max()) > 2.2 * hp.lr_eval:
+                bad.append(("adam " + k,))
+        else:
+            ok, err = _close(msd[k].cpu().double().numpy(), v.double().numpy(), 5e-5)
+            if not ok:
+                bad.append(("state " + k, err))
+    print(f"configs[4] cardiac B={B}, backward: gradient error / (3*e32 + 1e-4): median {np.median(ratios):.3f}, p90 {np.percentile(ratios, 90):.3f}, "
+          f"max {np.max(ratios):.3f}; float64 decides differently on {sum(v[0] for v in flips.values())} units")
+    assert not bad, f"{len(bad)} mismatches, first: {bad[:10]}"
+
+
 def test_five_step_trajectory_matches_oracle():
     """FIVE consecutive optimisation steps (zero_grad -> training_step -> backward -> Adam, STiLModel.py:228-386, :557-570) of a
     ResNet-18 case in the pseudo-label phase against the trajectory the REAL reference took on the same five seeded batches

@@ -37,103 +37,103 @@ __global__ void split_planes_kernel(const float* __restrict__ x, u16* __restrict
   }
 }
 
-// 128x128 block tile, 256 threads = 2x2 waves x (2x2 tiles of 32x32), BK = 32, one LDS buffer: [operand][plane][128 rows][40 bf16]
+// (64 TM) x (64 TN) block tile, 256 threads = 2x2 waves x (TM x TN tiles of 32x32), BK = 32, one LDS buffer:
+// [A planes 3][BM rows][40 bf16] then [W planes 3][BN rows][40 bf16]
 // ACC2: two-level accumulation as in the fp32 kernels (chains of 64 k into a partial accumulator, then into the master)
-template <bool FLY, bool ACC2>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void bf16x3_kernel(Args3 p) {
+template <int TM, int TN, bool FLY, bool ACC2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM * TN >= 4 ? 2 : (TM * TN == 2 ? 3 : 4)))) void bf16x3_kernel(Args3 p) {
   constexpr int LS = 40;                       // bf16 per LDS row: 64 B of data + 16 B pad (conflict-free ds_read_b128)
-  constexpr int PL = 128 * LS;                 // one plane of one operand
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int PLA = BM * LS, PLB = BN * LS;  // one plane of A / of W
   extern __shared__ __attribute__((aligned(16))) float lds_f[];
   __bf16* lds = reinterpret_cast<__bf16*>(lds_f);
-  const int nbn = p.N / 128, nbm = p.M / 128;
+  __bf16* ldsB = lds + 3 * PLA;
+  const int nbn = p.N / BN, nbm = p.M / BM;
   const int wg = xcd_remap(blockIdx.x, nbm * nbn);
   const int tm = wg / nbn, tn = wg - tm * nbn;
   const int tid = threadIdx.x, w = tid >> 6, wm = w >> 1, wn = w & 1, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  f32x4 st[FLY ? 8 : 12];                      // staged global loads of the next k-tile
+  constexpr int FA = BM / 32, FB = BN / 32;    // FLY: float4 per thread and k-tile
+  constexpr int PA = BM / 64, PB = BN / 64;    // planes: 16-byte chunks per thread, plane and k-tile
+  f32x4 st[FLY ? (FA + FB) : 3 * (PA + PB)];
   const long Mk = (long)p.M * p.K, Nk = (long)p.N * p.K;
   int k0 = 0;
   auto load = [&]() __attribute__((always_inline)) {
     if constexpr (FLY) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c = tid + 256 * i, row = c >> 3, q = c & 7;
-        st[i] = *reinterpret_cast<const f32x4*>(p.A + (long)(tm * 128 + row) * p.K + k0 + q * 4);
-        st[4 + i] = *reinterpret_cast<const f32x4*>(p.W + (long)(tn * 128 + row) * p.K + k0 + q * 4);
-      }
+      for (int i = 0; i < FA; ++i) { const int c = tid + 256 * i, row = c >> 3, q = c & 7; st[i] = *reinterpret_cast<const f32x4*>(p.A + (long)(tm * BM + row) * p.K + k0 + q * 4); }
+#pragma unroll
+      for (int i = 0; i < FB; ++i) { const int c = tid + 256 * i, row = c >> 3, q = c & 7; st[FA + i] = *reinterpret_cast<const f32x4*>(p.W + (long)(tn * BN + row) * p.K + k0 + q * 4); }
     } else {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
+      for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int c = tid + 256 * i, row = c >> 2, q = c & 3;
-          st[pl * 2 + i] = *reinterpret_cast<const f32x4*>(p.A3 + pl * Mk + (long)(tm * 128 + row) * p.K + k0 + q * 8);
-          st[6 + pl * 2 + i] = *reinterpret_cast<const f32x4*>(p.W3 + pl * Nk + (long)(tn * 128 + row) * p.K + k0 + q * 8);
-        }
+        for (int i = 0; i < PA; ++i) { const int c = tid + 256 * i, row = c >> 2, q = c & 3; st[pl * PA + i] = *reinterpret_cast<const f32x4*>(p.A3 + pl * Mk + (long)(tm * BM + row) * p.K + k0 + q * 8); }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) { const int c = tid + 256 * i, row = c >> 2, q = c & 3; st[3 * PA + pl * PB + i] = *reinterpret_cast<const f32x4*>(p.W3 + pl * Nk + (long)(tn * BN + row) * p.K + k0 + q * 8); }
+      }
     }
     k0 += 32;
   };
   auto lstore = [&]() __attribute__((always_inline)) {
     if constexpr (FLY) {
 #pragma unroll
-      for (int o = 0; o < 2; ++o)
+      for (int i = 0; i < FA + FB; ++i) {
+        const bool isB = i >= FA;
+        const int c = tid + 256 * (isB ? i - FA : i), row = c >> 3, q = c & 7;
+        bf16x4 h1, h2, h3;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int c = tid + 256 * i, row = c >> 3, q = c & 7;
-          bf16x4 h1, h2, h3;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { __bf16 a1, a2, a3; split3(st[o * 4 + i][e], a1, a2, a3); h1[e] = a1; h2[e] = a2; h3[e] = a3; }
-          __bf16* dst = lds + o * 3 * PL + row * LS + q * 4;
-          *reinterpret_cast<bf16x4*>(dst) = h1; *reinterpret_cast<bf16x4*>(dst + PL) = h2; *reinterpret_cast<bf16x4*>(dst + 2 * PL) = h3;
-        }
+        for (int e = 0; e < 4; ++e) { __bf16 a1, a2, a3; split3(st[i][e], a1, a2, a3); h1[e] = a1; h2[e] = a2; h3[e] = a3; }
+        __bf16* dst = (isB ? ldsB : lds) + row * LS + q * 4;
+        const int PL = isB ? PLB : PLA;
+        *reinterpret_cast<bf16x4*>(dst) = h1; *reinterpret_cast<bf16x4*>(dst + PL) = h2; *reinterpret_cast<bf16x4*>(dst + 2 * PL) = h3;
+      }
     } else {
 #pragma unroll
-      for (int o = 0; o < 2; ++o)
+      for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int i = 0; i < PA; ++i) { const int c = tid + 256 * i, row = c >> 2, q = c & 3; *reinterpret_cast<f32x4*>(lds + pl * PLA + row * LS + q * 8) = st[pl * PA + i]; }
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const int c = tid + 256 * i, row = c >> 2, q = c & 3;
-            *reinterpret_cast<f32x4*>(lds + (o * 3 + pl) * PL + row * LS + q * 8) = st[o * 6 + pl * 2 + i];
-          }
+        for (int i = 0; i < PB; ++i) { const int c = tid + 256 * i, row = c >> 2, q = c & 3; *reinterpret_cast<f32x4*>(ldsB + pl * PLB + row * LS + q * 8) = st[3 * PA + pl * PB + i]; }
+      }
     }
   };
   const int nk = p.K / 32;
   load();
   lstore();
   __syncthreads();
-  f32x16 part[2][2];
+  f32x16 part[TM][TN];
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) load();
     if (ACC2 && (kt & 1) == 0) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) part[i][j][r] = 0.f;
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 a[3][2], b[3][2];
+      bf16x8 a[3][TM], b[3][TN];
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
+      for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          a[pl][i] = *reinterpret_cast<const bf16x8*>(lds + pl * PL + (wm * 64 + i * 32 + li) * LS + s * 16 + lh * 8);
-          b[pl][i] = *reinterpret_cast<const bf16x8*>(lds + (3 + pl) * PL + (wn * 64 + i * 32 + li) * LS + s * 16 + lh * 8);
-        }
+        for (int i = 0; i < TM; ++i) a[pl][i] = *reinterpret_cast<const bf16x8*>(lds + pl * PLA + (wm * TM * 32 + i * 32 + li) * LS + s * 16 + lh * 8);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[pl][j] = *reinterpret_cast<const bf16x8*>(ldsB + pl * PLB + (wn * TN * 32 + j * 32 + li) * LS + s * 16 + lh * 8);
+      }
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {   // smallest terms first
+        for (int j = 0; j < TN; ++j) {   // smallest terms first
           f32x16& c = ACC2 ? part[i][j] : acc[i][j];
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);
@@ -146,16 +146,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void b
     }
     if (ACC2 && ((kt & 1) == 1 || kt + 1 == nk)) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] += part[i][j];
+        for (int j = 0; j < TN; ++j) acc[i][j] += part[i][j];
     }
     __syncthreads();
     if (kt + 1 < nk) lstore();
     __syncthreads();
   }
   Args q{nullptr, nullptr, p.C, p.M, p.N, p.K, 0, 0, nullptr, nullptr, nullptr};
-  Tile<2, 2, 32, 1>::store(q, lds_f, tm, tn, acc);
+  Tile<TM, TN, 32, 1>::store(q, lds_f, tm, tn, acc);
+}
+
+template <int TM, int TN, bool FLY, bool ACC2>
+static void launch_b3(const Args3& p) {
+  static bool attr = false;
+  if (!attr) { CK(hipFuncSetAttribute((const void*)bf16x3_kernel<TM, TN, FLY, ACC2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr = true; }
+  const size_t lds = std::max((size_t)3 * 64 * (TM + TN) * 40 * 2, (size_t)64 * 68 * 4);
+  hipLaunchKernelGGL((bf16x3_kernel<TM, TN, FLY, ACC2>), dim3((p.M / (64 * TM)) * (p.N / (64 * TN))), dim3(256), lds, 0, p);
 }
 
 int main(int argc, char** argv) {
@@ -184,18 +192,13 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&A3[i], maxA * 6)); CK(hipMalloc(&W3[i], maxW * 6));
     CK(hipMemcpy(A[i], hA.data(), maxA * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(W[i], hW.data(), maxW * 4, hipMemcpyHostToDevice));
   }
-  CK(hipFuncSetAttribute((const void*)bf16x3_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-  CK(hipFuncSetAttribute((const void*)bf16x3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-  CK(hipFuncSetAttribute((const void*)bf16x3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-  const size_t lds3 = (size_t)6 * 128 * 40 * 2;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   {   // warm the chip up
     Args p{A[0], W[0], C[0], 50176, 256, 2304, 0, 0, nullptr, nullptr, nullptr};
     for (int i = 0; i < 600; ++i) launch_tile<1, 1, 32, 1, 4>(p, 0);
     CK(hipDeviceSynchronize());
   }
-  printf("P = pre-split bf16 planes, F = split on the fly; two-level sums (chains of 64) unless '1-level'\n");
-  printf("%-24s %10s %10s %10s %11s %10s | relL2 vs float64: %9s %9s %9s %9s\n", "shape", "fp32 MFMA", "bf16x3 P", "bf16x3 F", "P 1-level", "split pass", "fp32 MFMA", "bf16x3 P", "bf16x3 F", "P 1-level");
+  printf("fp32 operands as 3 bf16 terms, 6 products on v_mfma_f32_32x32x16_bf16; P = pre-split bf16 planes in HBM, F = split on the fly while staging; two-level sums (chains of 64) unless '1-level'\n");
   for (auto& sh : shapes) {
     const size_t nA = (size_t)sh.M * sh.K, nW = (size_t)sh.N * sh.K, nC = (size_t)sh.M * sh.N;
     for (int i = 0; i < SETS; ++i) {   // planes of THIS shape's operands (the operands are the leading nA / nW floats of the buffers)
@@ -213,18 +216,26 @@ int main(int argc, char** argv) {
         for (int k = 0; k < sh.K; ++k) s += (double)a[k] * (double)w_[k];
         ref[(size_t)r * sh.N + n] = s;
       }
+    // variants: 0 fp32 MFMA 64x64 | P = pre-split planes, F = split on the fly; tile; two-level sums unless "1-level"
+    const char* names[] = {"fp32 64x64", "P 128x128", "F 128x128", "P 128x128 1-level", "F 64x128", "F 64x64", "F 128x64", "split pass"};
+    constexpr int NV = 8;
     auto launch = [&](int v, int set) {
-      if (v == 0) { Args p{A[set], W[set], C[set], sh.M, sh.N, sh.K, 0, 0, nullptr, nullptr, nullptr}; launch_tile<1, 1, 32, 1, 4>(p, 0); }
-      else {
-        Args3 p{A3[set], W3[set], A[set], W[set], C[set], sh.M, sh.N, sh.K};
-        if (v == 1) hipLaunchKernelGGL((bf16x3_kernel<false, true>), dim3((sh.M / 128) * (sh.N / 128)), dim3(256), lds3, 0, p);
-        else if (v == 2) hipLaunchKernelGGL((bf16x3_kernel<true, true>), dim3((sh.M / 128) * (sh.N / 128)), dim3(256), lds3, 0, p);
-        else hipLaunchKernelGGL((bf16x3_kernel<false, false>), dim3((sh.M / 128) * (sh.N / 128)), dim3(256), lds3, 0, p);
+      if (v == 0) { Args p{A[set], W[set], C[set], sh.M, sh.N, sh.K, 0, 0, nullptr, nullptr, nullptr}; launch_tile<1, 1, 32, 1, 4>(p, 0); return; }
+      Args3 p{A3[set], W3[set], A[set], W[set], C[set], sh.M, sh.N, sh.K};
+      switch (v) {
+        case 1: launch_b3<2, 2, false, true>(p); break;
+        case 2: launch_b3<2, 2, true, true>(p); break;
+        case 3: launch_b3<2, 2, false, false>(p); break;
+        case 4: launch_b3<1, 2, true, true>(p); break;
+        case 5: launch_b3<1, 1, true, true>(p); break;
+        case 6: launch_b3<2, 1, true, true>(p); break;
+        default: hipLaunchKernelGGL(split_planes_kernel, dim3(4096), dim3(256), 0, 0, A[set], A3[set], (long)nA);
       }
     };
-    double best[5] = {1e30, 1e30, 1e30, 1e30, 1e30}, err[4] = {0, 0, 0, 0};
+    double best[NV], err[NV];
+    for (int v = 0; v < NV; ++v) { best[v] = 1e30; err[v] = 0; }
     std::vector<float> out((size_t)RR * sh.N);
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < NV - 1; ++v) {
       CK(hipMemsetAsync(C[0], 0xff, nC * 4, 0));
       launch(v, 0);
       CK(hipDeviceSynchronize()); CK(hipGetLastError());
@@ -234,21 +245,17 @@ int main(int argc, char** argv) {
       err[v] = sqrt(num / den);
     }
     for (int r = 0; r < rounds; ++r)
-      for (int v = 0; v < 5; ++v) {
+      for (int v = 0; v < NV; ++v) {
         CK(hipEventRecord(e0, 0));
-        for (int it = 0; it < 6; ++it) {
-          const int set = (it + r) % SETS;
-          if (v < 4) launch(v, set);
-          else { hipLaunchKernelGGL(split_planes_kernel, dim3(4096), dim3(256), 0, 0, A[set], A3[set], (long)nA); }
-        }
+        for (int it = 0; it < 6; ++it) launch(v, (it + r) % SETS);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         best[v] = std::min(best[v], (double)ms / 6);
       }
     const double fl = 2.0 * sh.M * sh.N * sh.K;
-    char nm[64]; snprintf(nm, sizeof nm, "(%d, %d, %d)", sh.M, sh.N, sh.K);
-    printf("%-24s %7.1f TF %7.1f TF %7.1f TF %8.1f TF %7.0f us | %27.2e %9.2e %9.2e %9.2e\n", nm, fl / best[0] * 1e-9, fl / best[1] * 1e-9, fl / best[2] * 1e-9,
-           fl / best[3] * 1e-9, best[4] * 1e3, err[0], err[1], err[2], err[3]);
+    printf("(%d, %d, %d)\n", sh.M, sh.N, sh.K);
+    for (int v = 0; v < NV - 1; ++v) printf("   %-20s %7.1f TF   relL2 vs float64 %.2e\n", names[v], fl / best[v] * 1e-9, err[v]);
+    printf("   %-20s %7.0f us (A operand -> 3 bf16 planes)\n", names[NV - 1], best[NV - 1] * 1e3);
     fflush(stdout);
   }
   return 0;
