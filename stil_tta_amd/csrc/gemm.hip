@@ -75,6 +75,12 @@ struct GemmNTArgs {
   int splits;
   float* split_slabs;
   int* split_tickets;
+  // tile order (speed only; every tile computes the same bits wherever it runs): 0 = row-tile major (all column tiles of a row tile
+  // are consecutive, an XCD's contiguous range is a band of rows), n > 0 = column PANELS of n tiles, row-tile major inside a panel:
+  // an XCD's range is then (rows of a band) x (n column tiles), whose slice of W (n x 64 x K floats) stays in that XCD's L2 while
+  // the band's A row panels stream through once per panel.  Wide outputs with a W that does not fit the 4 MB L2 (N = 2048, K = 512:
+  // 4.2 MB) re-fetched W for every group of row tiles in flight: 794 MB per launch against 38 MB algorithmic (round-5 PMC).
+  int panel;
 };
 
 __device__ __forceinline__ float4 ld4_guard(const float* p, int nvalid, int vec) {
@@ -342,7 +348,13 @@ void gemm_nt_kernel(GemmNTArgs p) {
   if constexpr (TM * TN == 1) {   // a tile's slices are consecutive: same XCD (speed only)
     if (p.splits > 1) { split = wg % p.splits; wg /= p.splits; }
   }
-  const int tm = wg / nbn, tn = wg - tm * nbn;
+  int tm = wg / nbn, tn = wg - tm * nbn;
+  if (p.panel > 0) {   // block-uniform; nbn % panel == 0 (the launcher's condition)
+    const int per_panel = nbm * p.panel;
+    const int pn = wg / per_panel, rem = wg - pn * per_panel;
+    tm = rem / p.panel;
+    tn = pn * p.panel + (rem - tm * p.panel);
+  }
   const int tid = threadIdx.x, kq = tid % KQ, r0 = tid / KQ;
   const ConvGeom g = p.g;
 
@@ -954,6 +966,25 @@ static int nt_splits(int M, int N, int K, int tune) {
   if (s > 16) s = 16;
   return s < 2 ? 1 : s;
 }
+// column-panel width (in 64-column tiles) of the tile order, 0 = row-tile major.  Panels pay when W (N x K floats) does not fit an
+// XCD's 4 MB L2 beside the streaming A panels: then every group of row tiles in flight re-fetches all of W.  With panels of <= 1 MB
+// of W the price is A read once per panel instead of once: worth it while A x (panels - 1) is below what W's re-fetches cost, i.e.
+// for wide, short products (N >= 1024, K <= 1024).  STIL_GEMM_PANEL = -1 (automatic, default) | 0 (off) | n (forced, A/B).
+static int nt_panel(int M, int N, int K) {
+  static const int forced = [] { const char* e = getenv("STIL_GEMM_PANEL"); return e ? atoi(e) : -1; }();
+  const int nbn = cdiv(N, 64);
+  int gw = forced;
+  if (forced < 0) {
+    if (N < 1024 || K > 1024 || (long)N * K * 4 <= (2l << 20)) return 0;
+    gw = (int)((1l << 20) / (64l * K * 4));      // <= 1 MB of W per panel
+    if (gw < 4) gw = 4;
+  }
+  if (gw <= 0 || gw >= nbn) return 0;
+  while (gw > 1 && nbn % gw) --gw;                // whole panels only
+  (void)M;
+  return gw > 1 ? gw : 0;
+}
+
 // bytes of the split-K workspace stil_gemm_nt wants for this product (0: the product is not split).  Layout: a FIXED ticket
 // region of NT_SPLIT_TICKET_BYTES (one int per tile; split products have fewer than 256 tiles) then [tiles][splits][64*64] float
 // slabs -- fixed, so that one workspace can serve products of different shapes: no product's slabs ever overlap another's tickets.
@@ -988,6 +1019,7 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   p.os = out_stride < 1 ? 1 : out_stride; p.opy = out_py; p.opx = out_px; p.oOH = out_OH; p.oOW = out_OW;
   p.var = scale_var; p.var_eps = var_eps;
   p.splits = 1; p.split_slabs = nullptr; p.split_tickets = nullptr;
+  p.panel = 0;
   {
     const size_t need = stil_gemm_nt_split_workspace_bytes(M, N, K, tune_arg);
     if (split_ws && need > 0 && split_ws_bytes >= need && ((uintptr_t)split_ws % 256) == 0) {
@@ -1032,6 +1064,7 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   const bool vec = (cfg / 10000) % 10 == 1;
   rc = gemm_nt_attr();
   if (rc) return rc;
+  if (variant == 11 && p.splits == 1) p.panel = nt_panel(M, N, K);
   if (a_bn) {   // BatchNorm + ReLU of the producing layer applied while A is staged: 64x64 tiles, vector loads, BK = 16 only
     STIL_REQUIRE(vec && !bk32 && mode == 0 && srcC % 16 == 0 && srcC <= 2048 && (tune % 100 == 0 || tune % 100 == 11),
                  "stil_gemm_nt: a_bn runs 64x64 tiles only (tune %% 100 must be 0 or 11: the caller sizes colstats by "
