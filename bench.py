@@ -40,10 +40,11 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 def kernel_name(cfg: int) -> str:
     """stil_gemm_nt_config code -> the template instantiation rocprofv3 lists."""
     variant, bkd, acc2, vec, plain, bna = cfg % 100, (cfg // 100) % 10, (cfg // 1000) % 10, (cfg // 10000) % 10, (cfg // 100000) % 10, (cfg // 1000000) % 10
+    b3 = (cfg // 10000000) % 10      # the opt-in split-precision (bf16x3) instantiation
     bk32, nb = bkd >= 1, (1 if bkd == 2 else 2)   # bkd: 0 = 16-deep k-tiles, 1 = 32-deep in two LDS buffers, 2 = 32-deep in one
     tm, tn = {22: (2, 2), 21: (2, 1), 12: (1, 2), 11: (1, 1)}[variant]
     b = lambda v: "true" if v else "false"  # noqa: E731
-    return f"gemm_nt_kernel<{tm}, {tn}, {32 if bk32 else 16}, {b(vec)}, {b(acc2)}, {b(plain)}, {b(bna)}, {nb}>"
+    return f"gemm_nt_kernel<{tm}, {tn}, {32 if bk32 else 16}, {b(vec)}, {b(acc2)}, {b(plain)}, {b(bna)}, {nb}" + (", true>" if b3 else ">")
 
 
 def parse():
@@ -62,6 +63,10 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=32, help="batch of the CPU baseline (BASELINE.md section 3: 32; 256 = the bench's own batch, ~2 min per step)")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps after one warm-up (BASELINE.md section 3: >= 3)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (driver.GraphedTrainStep)")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
+                    help="fp32 = fp32-exact MFMA everywhere (the bench line, `value`); bf16x3 = the OPT-IN split-precision mode of the NT "
+                         "products (three bf16 terms per operand, six bf16 MFMAs, fp32 accumulate: at or below the fp32 chain's distance from "
+                         "float64); its line carries `precision` and is never the headline")
     ap.add_argument("--launch", choices=["auto", "eager", "graph"], default="auto",
                     help="auto: hipGraph replay when the per-GPU step is launch-bound (driver.wants_graph: batch x pixels), eager otherwise; "
                          "--graph = --launch graph")
@@ -299,6 +304,8 @@ def cpu_baseline(field_lengths, classes, img, batch, steps=3):
 
 def main():
     a = parse()
+    if a.precision == "bf16x3":      # before anything imports the operator layer (and inherited by the rank processes)
+        os.environ["STIL_PRECISION"] = "bf16x3"
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a))          # nothing below runs in the launcher; it has made no GPU call
     if a.launch_check:
@@ -465,11 +472,12 @@ def main():
         fps = FLOPS_PER_SAMPLE.get((a.img, a.ncat + a.ncon))
         out = dict(metric="training samples/sec (labeled+unlabeled) for DVM STiL", value=round(value, 2), unit="samples/s",
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(dt / a.steps * 1e3, 3),
-                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype=("f32" if a.precision == "fp32" else "f32 via bf16x3 split products"), data="synthetic",
                    config=dict(workload=f"config_{'cardiac' if a.variant == 'cardiac' else 'dvm'}_{dict(mmatch='MMatch', comatch='MultiCoMatch', simmatch='MultiSimMatch', freematch='MultiFreeMatch').get(a.variant, 'STiL')}{'_SAINT' if a.variant == 'saint' else ''} ResNet-50 + {'SAINT' if a.variant == 'saint' else 'Transformer'} tabular, B={a.batch}/GPU "
                                         f"({a.batch // 8} l + {a.batch - a.batch // 8} u), {a.img}px + {a.ncat + a.ncon} cols, K={a.classes}, "
                                         f"pseudo-label phase, MI dropout on",
-                               global_batch=a.batch * world, parallelism=f"dp{world}", precision="fp32-exact MFMA",
+                               global_batch=a.batch * world, parallelism=f"dp{world}", precision=("fp32-exact MFMA" if a.precision == "fp32" else
+                                          "bf16x3 split-precision NT products (OPT-IN; weight gradients fp32-exact MFMA) -- not the headline"),
                                launch="hipGraph replay" if a.graph else "eager", split_k=bool(__import__("stil_tta_amd.ops", fromlist=["_SPLITK"])._SPLITK),
                                input="host memory through data.DevicePrefetcher (PCIe-inclusive)" if a.host_input else "resident in HBM"),
                    ms_per_step_by_rank=[round(x / a.steps * 1e3, 3) for x in per_rank],

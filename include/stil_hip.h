@@ -86,13 +86,21 @@ int stil_gemm_nt_bstats_ok(const float* C, int N, int ldc, const float* resid, i
  *            rounding noise for long reductions): 0 = for K >= 512, 1 = never, 2 = always.
  *   + 10000  scalar epilogue (one dword per lane) instead of the 16-byte one 64x64 tiles use when N, ldc, ldr % 4 == 0 and
  *            every output-side pointer is 16-byte aligned (accumulators transposed through LDS; identical results).
+ *   + 100000 the OPT-IN split-precision mode ("bf16x3"): where a launch qualifies (64x64 tiles, 16-byte aligned operands, K % 32 == 0,
+ *            whole 32-channel taps) every staged fp32 operand element is split into three bf16 terms and a 32-deep k-tile is
+ *            2 x 6 v_mfma_f32_32x32x16_bf16 (fp32 accumulate, two-level sums) instead of 16 v_mfma_f32_32x32x2_f32; launches that
+ *            do not qualify run the fp32-exact kernels.  Distance from a float64 product at or below the fp32 chain's
+ *            (profiles/r05_bf16x3_lab.txt); results differ from the fp32-exact mode in the last bits.  Never the bench's `value`.
+ * Tile order (speed only, identical bits): row-tile major, or -- wide short products whose W exceeds an XCD's L2 (N >= 1024,
+ * K <= 1024, N K 4 B > 2 MB) -- column panels of <= 1 MB of W (STIL_GEMM_PANEL = -1 automatic | 0 off | n forced).
  * rows per output tile / tile variant stil_gemm_nt uses for an [M,N] output under `tune` (colstats granularity, bench bookkeeping) */
 int stil_gemm_nt_tile_rows(int M, int N, int tune);
 int stil_gemm_nt_variant(int M, int N, int tune);
 /* the instantiation stil_gemm_nt launches for these operands, as a CONFIG code whose digits are NOT the tune digits:
  * variant + 100 * bkd (0 = 16-deep k-tiles, 1 = 32-deep in two LDS buffers, 2 = 32-deep in one) + 1000 * acc2 (1 = two-level
  * sums, 0 = single chain) + 10000 * vec (16-byte loads; unrelated to tune's "+ 10000 scalar epilogue") + 100000 * plain (`plain` = 1: 1x1 / stride 1 / no padding / identity output map -- A is a plain row-major matrix
- * and the kernel's geometry code is compiled out) + 1000000 * a_bn (the operand-staging BatchNorm instantiation) */
+ * and the kernel's geometry code is compiled out) + 1000000 * a_bn (the operand-staging BatchNorm instantiation) + 10000000 * b3 (the
+ * split-precision instantiation, tune + 100000) */
 int stil_gemm_nt_config(const float* A, const float* W, int M, int N, int K, int lda, int ldb, int srcC, int KH, int KW, int plain, int a_bn, int tune);
 
 /* Weight gradient  dW (+)= dY[M,N]^T . Xgather[M,K]  (split over M, slab partials + ordered reduce).

@@ -85,6 +85,11 @@ _SPLITK = __import__("os").environ.get("STIL_SPLITK", "1") != "0"
 # per-call tuning arguments of stil_gemm_nt / stil_wgrad_tn (include/stil_hip.h); 0 = automatic.  Only the measurement
 # tools and bench.py's A/B environment knobs (STIL_GEMM_TUNE, STIL_WGRAD_TUNE) set them.
 TUNE = {"gemm": int(__import__("os").environ.get("STIL_GEMM_TUNE", "0")), "wgrad": int(__import__("os").environ.get("STIL_WGRAD_TUNE", "0"))}
+# STIL_PRECISION=bf16x3 (bench.py --precision bf16x3): the OPT-IN split-precision mode of the NT products (csrc/gemm.hip B3): + 100000 on
+# every stil_gemm_nt `tune`; launches that do not qualify (ragged / unaligned operands, other tiles) run the fp32-exact kernels.
+B3_FLAG = 100000
+if __import__("os").environ.get("STIL_PRECISION", "fp32") == "bf16x3":
+    TUNE["gemm"] += B3_FLAG
 
 
 class _SideStream:
@@ -214,7 +219,7 @@ _POLICY.sort(reverse=True)
 def _shape_tune(M, N, K, a_bn, has_tile_stats):
     """The `tune` argument of this product: TUNE["gemm"] when forced (measurement tools), else the first policy rule it meets."""
     t = TUNE["gemm"]
-    if t or a_bn or not _POLICY:
+    if t % B3_FLAG or a_bn or not _POLICY:
         return t
     for mink, tune in _POLICY:
         if K >= mink:
@@ -629,7 +634,7 @@ class ConvBnActFn(torch.autograd.Function):
 def _bstats_tune_ok() -> bool:
     """`bstats` rides in the 16-byte epilogue of 64x64 tiles only (stil_gemm_nt's STIL_REQUIRE): with a forced tile variant or the
     scalar epilogue (STIL_GEMM_TUNE, A/B measurements) the caller must take bn_train_bwd's own reduction pass instead."""
-    t = TUNE["gemm"]
+    t = TUNE["gemm"] % B3_FLAG
     return t < 10000 and t % 100 in (0, 11)
 
 
