@@ -44,7 +44,7 @@ def kernel_name(cfg: int) -> str:
     bk32, nb = bkd >= 1, (1 if bkd == 2 else 2)   # bkd: 0 = 16-deep k-tiles, 1 = 32-deep in two LDS buffers, 2 = 32-deep in one
     tm, tn = {22: (2, 2), 21: (2, 1), 12: (1, 2), 11: (1, 1)}[variant]
     b = lambda v: "true" if v else "false"  # noqa: E731
-    return f"gemm_nt_kernel<{tm}, {tn}, {32 if bk32 else 16}, {b(vec)}, {b(acc2)}, {b(plain)}, {b(bna)}, {nb}" + (", true>" if b3 else ">")
+    return f"gemm_nt_kernel<{tm}, {tn}, {32 if bk32 else 16}, {b(vec)}, {b(acc2)}, {b(plain)}, {b(bna)}, {nb}, {b(b3)}>"
 
 
 def parse():
