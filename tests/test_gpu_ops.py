@@ -53,6 +53,47 @@ def test_gemm_nt_plain(ops, M, N, K, act):
     close(pre, ref_pre, name="pre")
 
 
+@pytest.mark.parametrize("M,N,K,conv", [(1024, 256, 2048, False), (640, 128, 64, False), (4096, 2048, 512, False), (1024, 128, 9 * 128, True)])
+def test_gemm_nt_split_precision_mode_is_as_close_to_float64_as_the_fp32_chain(ops, M, N, K, conv):
+    """The OPT-IN split-precision mode (`tune` + 100000, STIL_PRECISION=bf16x3; csrc/gemm.hip B3): three bf16 terms per operand, six
+    bf16 MFMAs per term pair, fp32 accumulation, two-level sums.  Against a float64 product its relative L2 distance must be within
+    1.25x the fp32-exact kernel's on the same operands (measured: at or below it, profiles/r05_bf16x3_lab.txt), through the same
+    epilogue (bias + residual + ReLU), for a plain product, a short one, a wide one under the column-panel tile order and an
+    implicit-GEMM 3x3 convolution; and a launch that does not qualify (K % 32 != 0) silently runs the fp32-exact kernel."""
+    g = torch.Generator().manual_seed(M + K)
+    W, b = torch.randn(N, K, generator=g) * 0.05, torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g)
+    if conv:
+        C = K // 9
+        A4 = torch.randn(M // 64, 8, 8, C, generator=g)
+        A, geom = dev(A4), (8, 8, C, 8, 8, 3, 3, 1, 1, 0)
+        cols = F.unfold(A4.permute(0, 3, 1, 2).double(), 3, padding=1)                     # [n, C*9, 64], K index (c, tap)
+        A64 = cols.view(M // 64, C, 9, 64).permute(0, 3, 2, 1).reshape(M, K)               # rows (n, oy, ox), K index (tap, c)
+    else:
+        A, geom, A64 = dev(torch.randn(M, K, generator=g)), None, None
+        A64 = A.cpu().double()
+    ref = F.relu(A64 @ W.double().t() + b.double() + R.double())
+    rel = lambda x: float((x.cpu().double() - ref).norm() / ref.norm())
+    t0 = ops.TUNE["gemm"]
+    try:
+        ops.TUNE["gemm"] = t0 % ops.B3_FLAG
+        e32 = rel(ops.gemm_nt(A, dev(W), M, N, K, geom=geom, bias=dev(b), resid=dev(R), act=1))
+        ops.TUNE["gemm"] = t0 % ops.B3_FLAG + ops.B3_FLAG
+        out3 = ops.gemm_nt(A, dev(W), M, N, K, geom=geom, bias=dev(b), resid=dev(R), act=1)
+        e3 = rel(out3)
+        again = ops.gemm_nt(A, dev(W), M, N, K, geom=geom, bias=dev(b), resid=dev(R), act=1)
+        # a product the mode cannot take (K = 48: not a whole 32-deep k-tile) falls back to the fp32-exact kernel
+        A2, W2 = dev(torch.randn(300, 48, generator=g)), dev(torch.randn(70, 48, generator=g))
+        fb = ops.gemm_nt(A2, W2, 300, 70, 48)
+        ops.TUNE["gemm"] = t0 % ops.B3_FLAG
+        fb32 = ops.gemm_nt(A2, W2, 300, 70, 48)
+    finally:
+        ops.TUNE["gemm"] = t0
+    assert torch.equal(out3, again), "the split-precision product is not bit-identical on repetition"
+    assert torch.equal(fb, fb32), "a launch that does not qualify must run the fp32-exact kernel"
+    assert e3 <= 1.25 * e32 + 1e-8 and e3 < 5e-7, f"split precision {e3:.2e} from float64, fp32-exact chain {e32:.2e}"
+
+
 def test_gemm_nt_wide_epilogue_is_the_scalar_one_bit_for_bit(ops):
     """64x64 tiles stage their accumulators through LDS so that residual loads, `pre` stores and output stores are 16 bytes
     per lane (csrc/gemm.hip); `tune + 10000` keeps the one-dword-per-lane epilogue.  Same arithmetic per element: the two
