@@ -42,6 +42,8 @@ def kernel_name(cfg: int) -> str:
     variant, bkd, acc2, vec, plain, bna = cfg % 100, (cfg // 100) % 10, (cfg // 1000) % 10, (cfg // 10000) % 10, (cfg // 100000) % 10, (cfg // 1000000) % 10
     b3 = (cfg // 10000000) % 10      # the opt-in split-precision (bf16x3) instantiation
     bk32, nb = bkd >= 1, (1 if bkd == 2 else 2)   # bkd: 0 = 16-deep k-tiles, 1 = 32-deep in two LDS buffers, 2 = 32-deep in one
+    if variant == 44:                # the lean 128x128 kernel of the plain products
+        return f"gemm_nt_big_kernel<{'true' if acc2 else 'false'}, {'true' if bna else 'false'}>"
     tm, tn = {22: (2, 2), 21: (2, 1), 12: (1, 2), 11: (1, 1)}[variant]
     b = lambda v: "true" if v else "false"  # noqa: E731
     return f"gemm_nt_kernel<{tm}, {tn}, {32 if bk32 else 16}, {b(vec)}, {b(acc2)}, {b(plain)}, {b(bna)}, {nb}, {b(b3)}>"

@@ -712,6 +712,254 @@ void gemm_nt_kernel(GemmNTArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------
+// gemm_nt_big_kernel: the 128x128 block tile for PLAIN products (1x1 / stride-1 convolutions, nn.Linear) as a LEAN kernel of its
+// own -- 256 threads = 2x2 waves x (2x2 tiles of 32x32), 32-deep k-tiles in one LDS buffer, interior tiles only (M, N % 128 == 0,
+// K % 32 == 0, 16-byte aligned operands), ~220 registers = two waves per SIMD.  Why: two co-running launches of 128x128 tiles
+// reach 118-125 TF/s in aggregate where two of 64x64 tiles reach 109-117 (tests/tools/gemm_lab.hip `pair`, profiles/
+// r05_gemm_lab_pairs.txt) -- the other stream fills the big tile's tail and its steady state is better -- but the generic
+// kernel's 2x2 instantiation takes 212 + 64 registers (ONE wave per SIMD) and lost on the step for that reason.
+// Same k order and two-level sums as gemm_nt_kernel: the products are bit-identical to the 64x64 path's.  The per-tile statistics
+// keep their 64-row granularity (a wave row of the block IS one 64-row statistics tile: its sums need no LDS and no barrier; the
+// association of those sums differs from the 64x64 kernel's, the statistics agree to rounding).  Epilogue: every lane handles four
+// consecutive columns of a row (16-byte accesses) in four rounds, one 32x32 accumulator of each wave per round.
+template <bool ACC2, bool BNA>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_big_kernel(GemmNTArgs p) {
+  constexpr int BM = 128, BN = 128, BK = 32, LS = BK + 4, KQ = BK / 4, RP = 256 / KQ, RA = BM / RP, RB = BN / RP, TS = 68;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* As = lds;
+  float* Bs = lds + BM * LS;
+  float* tab = lds + (BM + BN) * LS;   // BNA: [3][C] = mean, a, beta of the producing layer
+  const int nbn = p.N / BN, nbm = p.M / BM;
+  const int wg = xcd_remap(blockIdx.x, nbm * nbn);
+  int tm = wg / nbn, tn = wg - tm * nbn;
+  if (p.panel > 0) {   // column panels of p.panel 128-column tiles (see GemmNTArgs::panel)
+    const int per_panel = nbm * p.panel;
+    const int pn = wg / per_panel, rem = wg - pn * per_panel;
+    tm = rem / p.panel;
+    tn = pn * p.panel + (rem - tm * p.panel);
+  }
+  const int tid = threadIdx.x, kq = tid % KQ, r0 = tid / KQ;
+  const int w = tid >> 6, wm = w >> 1, wn = w & 1, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+  const float* a_src[RA];
+  const float* b_src[RB];
+#pragma unroll
+  for (int i = 0; i < RA; ++i) a_src[i] = p.A + (long)(tm * BM + r0 + RP * i) * p.lda + kq * 4;
+#pragma unroll
+  for (int i = 0; i < RB; ++i) b_src[i] = p.Bw + (long)(tn * BN + r0 + RP * i) * p.ldb + kq * 4;
+  if constexpr (BNA) {
+    const int C = p.g.C;
+    for (int i = tid; i < 3 * C; i += 256) {
+      const int r = i / C, c = i - r * C;
+      tab[i] = p.abn[(r == 0 ? 0 : r + 1) * C + c];
+    }
+    __syncthreads();
+  }
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  f32x4v ra[RA], rb[RB];
+  int koff = 0, ra_c = 0;
+  auto load = [&]() __attribute__((always_inline)) {
+    if constexpr (BNA) ra_c = koff + kq * 4;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) ra[i] = *reinterpret_cast<const f32x4v*>(a_src[i] + koff);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) rb[i] = *reinterpret_cast<const f32x4v*>(b_src[i] + koff);
+    koff += BK;
+  };
+  auto lstore = [&]() __attribute__((always_inline)) {
+    if constexpr (BNA) {   // z = relu((y - mean) * a + beta), exactly as bn_apply_kernel / gemm_nt_kernel compute it
+      const int C = p.g.C;
+      const f32x4v mu = *reinterpret_cast<const f32x4v*>(tab + ra_c);
+      const f32x4v aa = *reinterpret_cast<const f32x4v*>(tab + C + ra_c);
+      const f32x4v bb = *reinterpret_cast<const f32x4v*>(tab + 2 * C + ra_c);
+#pragma unroll
+      for (int i = 0; i < RA; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ra[i][e] = fmaxf((ra[i][e] - mu[e]) * aa[e] + bb[e], 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4v*>(&As[(r0 + RP * i) * LS + kq * 4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4v*>(&Bs[(r0 + RP * i) * LS + kq * 4]) = rb[i];
+  };
+  auto compute = [&](f32x16 (&c)[2][2], auto fresh_tag) __attribute__((always_inline)) {
+    constexpr bool FRESH = decltype(fresh_tag)::value;
+    const float* Ab = As + (wm * 64 + li) * LS + lh * 4;
+    const float* Bb = Bs + (wn * 64 + li) * LS + lh * 4;
+#pragma unroll
+    for (int t = 0; t < BK / 8; ++t) {
+      f32x4v a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4v*>(Ab + i * 32 * LS + t * 8);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f32x4v*>(Bb + j * 32 * LS + t * 8);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (FRESH && t == 0) {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][0], b[j][0], zero, 0, 0, 0);
+          } else {
+            c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][0], b[j][0], c[i][j], 0, 0, 0);
+          }
+          c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][1], b[j][1], c[i][j], 0, 0, 0);
+          c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][2], b[j][2], c[i][j], 0, 0, 0);
+          c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][3], b[j][3], c[i][j], 0, 0, 0);
+        }
+      __builtin_amdgcn_s_setprio(0);
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int nk = p.K / BK;
+  load();
+  lstore();
+  __syncthreads();
+  if constexpr (!ACC2) {
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) load();
+      compute(acc, std::false_type{});
+      __syncthreads();
+      if (kt + 1 < nk) lstore();
+      __syncthreads();
+    }
+  } else {
+    for (int kt = 0; kt < nk; kt += 2) {   // chains of 64 products (two k-tiles) into `part`, then into the master: gemm_nt_kernel's order
+      f32x16 part[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (kt + u < nk) {
+          if (kt + u + 1 < nk) load();
+          if (u == 0) compute(part, std::true_type{}); else compute(part, std::false_type{});
+          __syncthreads();
+          if (kt + u + 1 < nk) lstore();
+          __syncthreads();
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] += part[i][j];
+    }
+  }
+
+  // ---- per-tile column statistics of the raw product (training BatchNorm): wave row wm IS the 64-row statistics tile 2 tm + wm
+  if (p.colstats) {
+    const int ts = tm * 2 + wm;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc += acc[i][j][r] * p.alpha;
+      sacc += __shfl_xor(sacc, 32, 64);
+      const float mean = sacc / 64.f;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float d = acc[i][j][r] * p.alpha - mean; q += d * d; }
+      q += __shfl_xor(q, 32, 64);
+      if (lh == 0) {
+        const int col = tn * BN + wn * 64 + j * 32 + li;
+        p.colstats[((long)ts * 2) * p.N + col] = mean;
+        p.colstats[((long)ts * 2 + 1) * p.N + col] = q;
+      }
+    }
+  }
+
+  // ---- epilogue in four rounds: round (i, j) gathers acc[i][j] of the four waves into a virtual 64x64 tile in LDS
+  float* T = lds;
+  const int cq = (tid & 15) * 4, rt = tid >> 4;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f), one4 = make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = tn * BN + (cq >> 5) * 64 + j * 32 + (cq & 31);
+    const float4 bia = p.bias ? *reinterpret_cast<const float4*>(p.bias + col) : zero4;
+    const float4 sb = p.sub ? *reinterpret_cast<const float4*>(p.sub + col) : zero4;
+    float4 sc = p.scale ? *reinterpret_cast<const float4*>(p.scale + col) : one4;
+    if (p.var) {
+      const float4 vv = *reinterpret_cast<const float4*>(p.var + col);
+      sc.x = sc.x / sqrtf(vv.x + p.var_eps); sc.y = sc.y / sqrtf(vv.y + p.var_eps);
+      sc.z = sc.z / sqrtf(vv.z + p.var_eps); sc.w = sc.w / sqrtf(vv.w + p.var_eps);
+    }
+    const float4 sh = p.shift ? *reinterpret_cast<const float4*>(p.shift + col) : zero4;
+    float4 bs1[2], bs2[2];   // BatchNorm-backward sums of this thread's rows, per 64-row statistics tile (half 0: rows < 64 of the block)
+    bs1[0] = bs1[1] = bs2[0] = bs2[1] = zero4;
+    float4 bmu = zero4, brs = zero4, bap = zero4, bbp = zero4;
+    if (p.bstats) {
+      bmu = *reinterpret_cast<const float4*>(p.bs_stats + col);
+      brs = *reinterpret_cast<const float4*>(p.bs_stats + p.N + col);
+      bap = *reinterpret_cast<const float4*>(p.bs_stats + 2 * p.N + col);
+      bbp = *reinterpret_cast<const float4*>(p.bs_stats + 3 * p.N + col);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) T[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * TS + wn * 32 + li] = acc[i][j][r];
+      __syncthreads();
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int rl = ps * 16 + rt;
+        const long row = (long)tm * BM + (rl >> 5) * 64 + i * 32 + (rl & 31);
+        float4 v = *reinterpret_cast<const float4*>(T + rl * TS + cq);
+        v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
+        v.x = (v.x - sb.x) * sc.x + sh.x + bia.x; v.y = (v.y - sb.y) * sc.y + sh.y + bia.y;
+        v.z = (v.z - sb.z) * sc.z + sh.z + bia.z; v.w = (v.w - sb.w) * sc.w + sh.w + bia.w;
+        if (p.resid) {
+          const float4 rr = *reinterpret_cast<const float4*>(p.resid + row * p.ldr + col);
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        if (p.pre) *reinterpret_cast<float4*>(p.pre + row * p.ldc + col) = v;
+        if (p.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        else if (p.act == 2) { v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w); }
+        if (p.rmask) {
+          const float4 mk = *reinterpret_cast<const float4*>(p.rmask + row * p.ldm + col);
+          v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+        }
+        *reinterpret_cast<float4*>(p.C + row * p.ldc + col) = v;
+        if (p.bstats) {   // block-uniform
+          const float4 yy = *reinterpret_cast<const float4*>(p.bs_y + row * p.ldbs + col);
+          float4 gg = v;
+          if (p.bs_relu == 2) {
+            gg.x = ((yy.x - bmu.x) * bap.x + bbp.x) > 0.f ? gg.x : 0.f; gg.y = ((yy.y - bmu.y) * bap.y + bbp.y) > 0.f ? gg.y : 0.f;
+            gg.z = ((yy.z - bmu.z) * bap.z + bbp.z) > 0.f ? gg.z : 0.f; gg.w = ((yy.w - bmu.w) * bap.w + bbp.w) > 0.f ? gg.w : 0.f;
+          }
+          const int hf = ps >> 1;   // rl < 32: statistics tile 2 tm, else 2 tm + 1 (compile-time after unrolling)
+          bs1[hf].x += gg.x; bs2[hf].x += gg.x * ((yy.x - bmu.x) * brs.x);
+          bs1[hf].y += gg.y; bs2[hf].y += gg.y * ((yy.y - bmu.y) * brs.y);
+          bs1[hf].z += gg.z; bs2[hf].z += gg.z * ((yy.z - bmu.z) * brs.z);
+          bs1[hf].w += gg.w; bs2[hf].w += gg.w * ((yy.w - bmu.w) * brs.w);
+        }
+      }
+    }
+    if (p.bstats) {   // 16 row-threads per column quad -> LDS -> one fixed-order sum per column, statistics tile and sum (deterministic)
+      __syncthreads();
+      float* R = lds;   // [4 = (half, which)][16][64]
+      *reinterpret_cast<float4*>(R + (0 * 16 + rt) * 64 + cq) = bs1[0];
+      *reinterpret_cast<float4*>(R + (1 * 16 + rt) * 64 + cq) = bs2[0];
+      *reinterpret_cast<float4*>(R + (2 * 16 + rt) * 64 + cq) = bs1[1];
+      *reinterpret_cast<float4*>(R + (3 * 16 + rt) * 64 + cq) = bs2[1];
+      __syncthreads();
+      const int c = tid & 63, q4 = tid >> 6, hf = q4 >> 1, which = q4 & 1;
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += R[(q4 * 16 + r) * 64 + c];
+      const int gc = tn * BN + (c >> 5) * 64 + j * 32 + (c & 31);
+      p.bstats[((long)(p.bs_tile0 + tm * 2 + hf) * 2 + which) * p.N + gc] = t;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 struct GemmTNArgs {
   const float* Y;  // [M, N], row stride ldy
   const float* X;  // gather source (NHWC, row stride ldx) -- geometry g, mode 0
@@ -977,6 +1225,19 @@ static int gemm_nt_attr() {
   return STIL_OK;
 }
 
+// The lean 128x128 kernel (gemm_nt_big_kernel) takes a PLAIN product when: it is asked for (tune % 100 == 44, or STIL_GEMM_BIG=1 with
+// the tile left automatic), every tile is interior (M, N % 128 == 0), K % 32 == 0, operands are 16-byte aligned, and the grid is
+// large enough to fill the chip (>= `min_tiles` tiles of 128x128).  The launcher additionally needs the 16-byte epilogue's conditions.
+static bool nt_big_wanted(int M, int N, int K, bool plain, bool vec, int srcC, int tune) {
+  static const int env_big = [] { const char* e = getenv("STIL_GEMM_BIG"); return e ? atoi(e) : 0; }();   // 0 off, n > 0: on from n tiles
+  static const int env_mink = [] { const char* e = getenv("STIL_GEMM_BIG_MINK"); return e ? atoi(e) : 0; }();   // automatic mode: only K >= this
+  const int forced = tune % 100;
+  if (forced != 44 && !(forced == 0 && env_big > 0)) return false;
+  if (!plain || !vec || (M % 128) || (N % 128) || (K % 32) || srcC != K) return false;
+  const long tiles = (long)(M / 128) * (N / 128);
+  return forced == 44 || (tiles >= env_big && K >= env_mink);
+}
+
 // `tune` (per call, 0 = automatic; for A/B measurements): variant + 100 * bk32 + 1000 * acc2
 //   variant: block tile 22 = 128x128, 21 = 128x64, 11 = 64x64;  bk32: 1 = 32-deep LDS tiles (default 16);
 //   acc2: 1 = single-chain accumulation, 2 = two-level accumulation, 0 = two-level for K >= 512
@@ -985,6 +1246,7 @@ extern "C" int stil_gemm_nt_variant(int M, int N, int tune) {
   tune %= 10000;   // + 10000 = scalar epilogue: no bearing on the tile
   const int forced = tune % 100;
   if (forced == 11 || forced == 21 || forced == 22 || forced == 12) return forced;
+  // 44 (the lean 128x128 kernel for plain products) keeps the 64-row statistics granularity and falls back to 64x64 where it does not apply
   // measured (tests/tools/gemm_bench.py, profiles/r02t-u): with 6 waves per SIMD the 64x64 tile is at least as fast as
   // 128x64 / 128x128 on every shape of the step (occupancy + tile quantisation over 256 CUs outweigh operand reuse).
   (void)M; (void)N;
@@ -1004,8 +1266,8 @@ extern "C" int stil_gemm_nt_tile_rows(int M, int N, int tune) { const int v = st
 // The kernel instantiation stil_gemm_nt launches for these operands, as variant + 100 * bk32 + 1000 * acc2 + 10000 * vec +
 // 100000 * plain + 1000000 * a_bn (bench bookkeeping: names the rocprofv3 row of a launch).  `plain`: 1x1 / stride 1 / no padding / identity
 // output map, i.e. A is a plain row-major matrix.  The launcher below calls the same function.
-extern "C" int stil_gemm_nt_config(const float* A, const float* W, int M, int N, int K, int lda, int ldb, int srcC, int KH, int KW,
-                                   int plain, int a_bn, int tune) {
+static int nt_config(const float* A, const float* W, int M, int N, int K, int lda, int ldb, int srcC, int KH, int KW,
+                     int plain, int a_bn, int tune, bool allow_big) {
   const bool want_b3 = tune >= 100000;   // the opt-in split-precision mode: reported as + 10000000 where the launch qualifies
   tune %= 10000;
   const int variant = stil_gemm_nt_variant(M, N, tune);
@@ -1020,12 +1282,19 @@ extern "C" int stil_gemm_nt_config(const float* A, const float* W, int M, int N,
   const bool single = bk32 && (bkd == 3 || bkd == 0);
   const bool acc2 = tune / 1000 == 2 || (tune / 1000 == 0 && K >= 512);
   const bool vec = is_vec(A, lda) && (srcC % 4 == 0) && is_vec(W, ldb) && (K % 4 == 0);  // every 16-byte load aligned and entirely in or out
+  if (allow_big && !want_b3 && nt_big_wanted(M, N, K, plain && KH * KW == 1, vec, srcC, tune) && (long)cdiv(M, 64) * cdiv(N, 64) >= 256)
+    return 44 + 200 + 1000 * (acc2 ? 1 : 0) + 10000 + 100000 + (a_bn ? 1000000 : 0);
   const bool b3 = want_b3 && vec && variant == 11 && K % 32 == 0 && (KH * KW == 1 || srcC % 32 == 0) && (!a_bn || srcC % 32 == 0);
   if (b3)     // 64x64, 32-deep, one buffer, two-level sums (+ operand-staging BatchNorm)
     return 11 + 200 + 1000 + 10000 + 100000 * ((plain && KH * KW == 1) ? 1 : 0) + (a_bn ? 1000000 : 0) + 10000000;
   if (a_bn)   // operand-staging BatchNorm: 64x64 tiles, BK = 16 (see stil_gemm_nt)
     return 11 + 1000 * (acc2 ? 1 : 0) + 10000 * (vec ? 1 : 0) + 100000 * ((plain && KH * KW == 1) ? 1 : 0) + 1000000;
   return variant + 100 * ((vec && bk32) ? (single ? 2 : 1) : 0) + 1000 * (acc2 ? 1 : 0) + 10000 * (vec ? 1 : 0) + 100000 * ((plain && KH * KW == 1) ? 1 : 0);
+}
+
+extern "C" int stil_gemm_nt_config(const float* A, const float* W, int M, int N, int K, int lda, int ldb, int srcC, int KH, int KW,
+                                   int plain, int a_bn, int tune) {
+  return nt_config(A, W, M, N, K, lda, ldb, srcC, KH, KW, plain, a_bn, tune, true);
 }
 
 // split-K policy: only 64x64 tiles whose grid would leave most CUs idle (fewer than one workgroup per CU) and whose reduction is
@@ -1085,7 +1354,7 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   const int tune = tune_arg % 10000;                 // + 10000: scalar (one dword per lane) epilogue, for A/B measurements and tests
   const bool scalar_epilogue = tune_arg / 10000 == 1;
   STIL_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0, "stil_gemm_nt: null pointer or empty shape (M=%d N=%d K=%d)", M, N, K);
-  STIL_REQUIRE(tune_arg >= 0 && tune_arg < 20000 && tune < 3000 && (tune % 100 == 0 || tune % 100 == 11 || tune % 100 == 21 || tune % 100 == 22 || tune % 100 == 12) && (tune / 100) % 10 <= 3,
+  STIL_REQUIRE(tune_arg >= 0 && tune_arg < 20000 && tune < 3000 && (tune % 100 == 0 || tune % 100 == 11 || tune % 100 == 21 || tune % 100 == 22 || tune % 100 == 12 || tune % 100 == 44) && (tune / 100) % 10 <= 3,
                "stil_gemm_nt: bad tune %d", tune);
   STIL_REQUIRE(KH * KW * srcC == K, "stil_gemm_nt: K=%d != KH*KW*C=%d", K, KH * KW * srcC);
   STIL_REQUIRE(M % (OH * OW) == 0, "stil_gemm_nt: M=%d not a multiple of OH*OW=%d", M, OH * OW);
@@ -1120,7 +1389,7 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   }
   p.bs_y = bs_y; p.bs_stats = bs_stats; p.bstats = bstats; p.ldbs = ldc; p.bs_relu = bs_relu; p.bs_tile0 = bs_tile0;
   STIL_REQUIRE(!bstats || (bs_y && bs_stats && (bs_relu == 0 || bs_relu == 2) && bs_tile0 >= 0 && !colstats && !a_bn && p.wide &&
-                           ((uintptr_t)bs_y % 16) == 0 && ((uintptr_t)bs_stats % 16) == 0 && (tune % 100 == 0 || tune % 100 == 11)),
+                           ((uintptr_t)bs_y % 16) == 0 && ((uintptr_t)bs_stats % 16) == 0 && (tune % 100 == 0 || tune % 100 == 11 || tune % 100 == 44)),
                "stil_gemm_nt: bstats needs bs_y / bs_stats, bs_relu 0 or 2, the 16-byte epilogue on 64x64 tiles (stil_gemm_nt_bstats_ok) "
                "and excludes colstats / a_bn");
   STIL_REQUIRE(!colstats || (p.os == 1 && !bias && !sub && !scale && !shift && !resid && act == 0),
@@ -1132,7 +1401,7 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   hipStream_t s = (hipStream_t)stream;
   // plain row-major A and identity output map: the geometry code is compiled out (gemm_nt_kernel<..., PLAIN>)
   const bool plain = KH * KW == 1 && stride == 1 && pad_y == 0 && pad_x == 0 && mode == 0 && p.os == 1 && srcH == OH && srcW == OW;
-  const int cfg = stil_gemm_nt_config(A, W, M, N, K, lda, ldb, srcC, KH, KW, plain ? 1 : 0, a_bn ? 1 : 0, tune);
+  const int cfg = nt_config(A, W, M, N, K, lda, ldb, srcC, KH, KW, plain ? 1 : 0, a_bn ? 1 : 0, tune, false);   // (the lean 128x128 kernel is decided below)
   const int variant = cfg % 100;
   const bool bk32 = (cfg / 100) % 10 >= 1;   // BK = 32: whole 128-byte lines per staged row; needs whole taps and vector loads
   const bool single = (cfg / 100) % 10 == 2; // ... with one LDS buffer (64x64 tiles only)
@@ -1141,8 +1410,26 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
   rc = gemm_nt_attr();
   if (rc) return rc;
   if (variant == 11 && p.splits == 1) p.panel = nt_panel(M, N, K);
+  if (!want_b3 && variant == 11 && p.splits == 1 && p.wide && !scalar_epilogue && mode == 0 && (!a_bn || srcC <= 2048) &&
+      nt_big_wanted(M, N, K, plain, vec, srcC, tune) && (long)cdiv(M, 64) * cdiv(N, 64) >= 256) {
+    p.panel = (p.panel > 0 && p.panel % 2 == 0 && (N / 128) % (p.panel / 2) == 0) ? p.panel / 2 : 0;   // panels in 128-column tiles
+    const dim3 grid_((M / 128) * (N / 128));
+    const size_t lds_ = (size_t)256 * 36 * sizeof(float) + (a_bn ? (size_t)3 * srcC * sizeof(float) : 0);
+    static bool attr_ = false;
+    if (!attr_) {
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      attr_ = true;
+    }
+    if (acc2 && a_bn) hipLaunchKernelGGL((gemm_nt_big_kernel<true, true>), grid_, dim3(256), lds_, s, p);
+    else if (acc2) hipLaunchKernelGGL((gemm_nt_big_kernel<true, false>), grid_, dim3(256), lds_, s, p);
+    else if (a_bn) hipLaunchKernelGGL((gemm_nt_big_kernel<false, true>), grid_, dim3(256), lds_, s, p);
+    else hipLaunchKernelGGL((gemm_nt_big_kernel<false, false>), grid_, dim3(256), lds_, s, p);
+    STIL_LAUNCH_CHECK();
+    return STIL_OK;
+  }
   if (a_bn) {   // BatchNorm + ReLU of the producing layer applied while A is staged: 64x64 tiles, vector loads, BK = 16 only
-    STIL_REQUIRE(vec && !bk32 && mode == 0 && srcC % 16 == 0 && srcC <= 2048 && (tune % 100 == 0 || tune % 100 == 11),
+    STIL_REQUIRE(vec && !bk32 && mode == 0 && srcC % 16 == 0 && srcC <= 2048 && (tune % 100 == 0 || tune % 100 == 11 || tune % 100 == 44),
                  "stil_gemm_nt: a_bn runs 64x64 tiles only (tune %% 100 must be 0 or 11: the caller sizes colstats by "
                  "stil_gemm_nt_tile_rows) and needs 16-byte aligned operands, a forward gather, Cin %% 16 == 0 and Cin <= 2048 (Cin=%d)", srcC);
     const dim3 grid_(cdiv(M, 64) * cdiv(N, 64) * p.splits);

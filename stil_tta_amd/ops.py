@@ -223,7 +223,7 @@ def _shape_tune(M, N, K, a_bn, has_tile_stats):
         return t
     for mink, tune in _POLICY:
         if K >= mink:
-            if tune % 100 not in (0, 11) and (has_tile_stats or M % 128 or N % 128):   # per-tile statistics (64-row tiles) / ragged tiles stay on 64x64
+            if tune % 100 not in (0, 11, 44) and (has_tile_stats or M % 128 or N % 128):   # per-tile statistics (64-row tiles) / ragged tiles stay on 64x64
                 return t
             return tune
     return t
@@ -635,7 +635,7 @@ def _bstats_tune_ok() -> bool:
     """`bstats` rides in the 16-byte epilogue of 64x64 tiles only (stil_gemm_nt's STIL_REQUIRE): with a forced tile variant or the
     scalar epilogue (STIL_GEMM_TUNE, A/B measurements) the caller must take bn_train_bwd's own reduction pass instead."""
     t = TUNE["gemm"] % B3_FLAG
-    return t < 10000 and t % 100 in (0, 11)
+    return t < 10000 and t % 100 in (0, 11, 44)
 
 
 def _bstat_tiles(Nb, H, W_, k, stride, pad):

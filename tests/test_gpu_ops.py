@@ -134,6 +134,63 @@ def test_gemm_nt_wide_epilogue_is_the_scalar_one_bit_for_bit(ops):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("M,N,K", [(1280, 256, 64), (512, 384, 1024), (2048, 2048, 512), (384, 128, 96)])
+def test_gemm_nt_lean_128x128_kernel_equals_the_64x64_path(ops, M, N, K):
+    """gemm_nt_big_kernel (`tune` 44: the 128x128 block tile of the plain products as a lean kernel of its own) against the 64x64
+    path on the same operands: the PRODUCT bit for bit through every epilogue form (same k order, same two-level sums; alpha,
+    eval-BatchNorm affine from the running variance, bias, residual, stored pre-activation, ReLU / GELU, ReLU mask; the
+    operand-staging BatchNorm; the column-panel tile order of the wide case), the 64-row tile statistics (forward mean / M2, backward
+    sums) to rounding -- a wave row of the block sums its 64 rows in registers where the 64x64 kernel combines two waves through
+    LDS -- and against float64.  (384, 128, 96): fewer than 256 tiles of 64x64, so `tune` 44 falls back to the 64x64 kernel itself.)"""
+    g = torch.Generator().manual_seed(M + N + K)
+    A, W = dev(torch.randn(M, K, generator=g)), dev(torch.randn(N, K, generator=g) * 0.1)
+    bias, sub, scale, shift = (dev(torch.randn(N, generator=g)) for _ in range(4))
+    var = dev(torch.rand(N, generator=g) + 0.5)
+    R, mask = dev(torch.randn(M, N, generator=g)), dev(torch.randn(M, N, generator=g))
+    y = torch.randn(M, N, generator=g) * 2 + 0.3
+    mean, rstd = y.mean(0), 1.0 / torch.sqrt(y.var(0, unbiased=False) + 1e-5)
+    gamma, beta = 0.5 + torch.rand(N, generator=g), 0.2 * torch.randn(N, generator=g)
+    stats = dev(torch.stack([mean, rstd, gamma * rstd, beta]).contiguous())
+    yd = dev(y)
+    nt = M // 64
+    # operand-staging BatchNorm: A is the raw output of a producing layer with its statistics block [4][K]
+    a_stats = dev(torch.stack([torch.randn(K, generator=g) * 0.1, torch.rand(K, generator=g) + 0.5, torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1]).contiguous())
+    outs = {}
+    t0 = ops.TUNE["gemm"]
+    try:
+        for tune in (11, 44):
+            ops.TUNE["gemm"] = tune
+            pre = torch.empty(M, N, device="cuda")
+            o1 = ops.gemm_nt(A, W, M, N, K, bias=bias, sub=sub, scale=scale, scale_var=var, var_eps=1e-5, shift=shift, resid=R, pre=pre, act=2, alpha=0.7)
+            o2 = ops.gemm_nt(A, W, M, N, K, resid=R, act=1)
+            ts = torch.zeros(2 * nt, N, device="cuda")
+            raw = ops.gemm_nt(A, W, M, N, K, colstats=ts)
+            part = torch.zeros(2 * nt, N, device="cuda")
+            gmask = ops.gemm_nt(A, W, M, N, K, resid=R, relu_mask=mask, bstats=(yd, stats, part, 0, 0))
+            part2 = torch.zeros(2 * nt, N, device="cuda")
+            g2 = ops.gemm_nt(A, W, M, N, K, bstats=(yd, stats, part2, 2, 0))
+            ts_bn = torch.zeros(2 * nt, N, device="cuda")
+            bna = ops.gemm_nt(A, W, M, N, K, a_bn=a_stats, colstats=ts_bn) if K % 32 == 0 and K % 16 == 0 else raw
+            outs[tune] = [t.clone() for t in (o1, pre, o2, raw, gmask, g2, bna, ts, part, part2, ts_bn)]
+    finally:
+        ops.TUNE["gemm"] = t0
+    names = ("affine+bias+resid+gelu", "pre", "resid+relu", "raw", "resid+mask", "plain gradient", "operand-staging BN")
+    for i, nm in enumerate(names):
+        assert torch.equal(outs[11][i], outs[44][i]), f"{nm}: the 128x128 kernel's product differs from the 64x64 path at {(M, N, K)}"
+    for i, nm in ((7, "forward tile statistics"), (8, "backward sums, mask carried"), (9, "backward sums, mask recomputed"), (10, "forward tile statistics under operand-staging BN")):
+        a, b = outs[11][i].double().cpu(), outs[44][i].double().cpu()
+        sc = float(a.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 2e-5 * sc, f"{nm}: {float((a - b).abs().max()):.3e} of {sc:.3e} at {(M, N, K)}"
+    # and the statistics against float64 on the 128x128 path's own product
+    raw64 = outs[44][3].double().cpu()
+    got = outs[44][7].double().cpu().view(nt, 2, N)
+    for t in (0, nt // 2, nt - 1):
+        rows = raw64[64 * t: 64 * t + 64]
+        assert float((got[t, 0] - rows.mean(0)).abs().max()) <= 1e-5 * (1 + float(rows.abs().max()))
+        assert float((got[t, 1] - ((rows - rows.mean(0)) ** 2).sum(0)).abs().max()) <= 1e-4 * (1 + float((rows ** 2).sum(0).max()))
+    close(outs[44][2], F.relu(A.cpu() @ W.cpu().t() + R.cpu()), name="128x128 vs ATen")
+
+
 CONVS = [  # Cin, Cout, k, stride, pad, H
     (64, 64, 1, 1, 0, 14), (64, 128, 1, 2, 0, 14), (32, 64, 3, 1, 1, 9), (64, 48, 3, 2, 1, 14), (16, 32, 3, 2, 1, 7),
     (128, 256, 3, 1, 1, 4),

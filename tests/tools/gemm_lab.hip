@@ -293,9 +293,65 @@ static bool launch_streamk(const Args& p0, hipStream_t s) {
 }
 
 #ifndef GEMM_LAB_NO_MAIN
+// `gemm_lab pair`: two GEMMs of one shape on TWO streams at the same time (as the step runs them: input gradients beside weight
+// gradients, student beside teacher) -- the aggregate rate of the pair against each structure alone.
+static void pair_mode(float** A, float** W, float** C, float* slabs, int* tickets) {
+  struct PV { const char* name; bool (*launch)(const Args&, hipStream_t); };
+  PV pv[] = {{"64x64 bk32 nb1", launch_tile<1, 1, 32, 1, 4>}, {"128x64 bk32 nb1", launch_tile<2, 1, 32, 1, 3>}, {"128x128 bk32 nb1", launch_tile<2, 2, 32, 1, 2>},
+             {"128x128 bk16 nb2", launch_tile<2, 2, 16, 2, 2>}};
+  Shape shapes[] = {{50176, 256, 2304, ""}, {12544, 512, 4608, ""}, {50176, 1024, 256, ""}, {16640, 2048, 512, ""}, {200704, 128, 512, ""}};
+  hipStream_t s1, s2; CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
+  hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
+  const int INNER = 6;
+  for (auto& sh : shapes) {
+    printf("\n(%d, %d, %d): TF/s alone | aggregate TF/s of two co-running launches (one per stream)\n", sh.M, sh.N, sh.K);
+    const double fl = 2.0 * sh.M * sh.N * sh.K;
+    for (auto& x : pv) {
+      double alone = 1e30, both = 1e30;
+      for (int r = 0; r < 4; ++r) {
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, s1));
+        for (int it = 0; it < INNER; ++it) { Args p{A[it % 3], W[it % 3], C[it % 3], sh.M, sh.N, sh.K, 0, 0, slabs, tickets, nullptr}; x.launch(p, s1); }
+        CK(hipEventRecord(e1, s1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        alone = std::min(alone, (double)ms / INNER);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, s1));
+        CK(hipStreamWaitEvent(s2, e0, 0));
+        for (int it = 0; it < INNER; ++it) {
+          Args p{A[0], W[0], C[0], sh.M, sh.N, sh.K, 0, 0, slabs, tickets, nullptr}; x.launch(p, s1);
+          Args q{A[1], W[1], C[1], sh.M, sh.N, sh.K, 0, 0, slabs, tickets, nullptr}; x.launch(q, s2);
+        }
+        CK(hipEventRecord(e1, s1)); CK(hipEventRecord(e2, s2));
+        CK(hipEventSynchronize(e1)); CK(hipEventSynchronize(e2));
+        float m1, m2; CK(hipEventElapsedTime(&m1, e0, e1)); CK(hipEventElapsedTime(&m2, e0, e2));
+        both = std::min(both, (double)std::max(m1, m2) / INNER);
+      }
+      printf("   %-20s alone %6.1f TF | pair %6.1f TF aggregate (%.2fx the time of one launch)\n", x.name, fl / alone * 1e-9, 2 * fl / both * 1e-9, both / alone);
+    }
+    // mixed pair: 64x64 beside 128x128
+    {
+      double both = 1e30;
+      for (int r = 0; r < 4; ++r) {
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, s1)); CK(hipStreamWaitEvent(s2, e0, 0));
+        for (int it = 0; it < INNER; ++it) {
+          Args p{A[0], W[0], C[0], sh.M, sh.N, sh.K, 0, 0, slabs, tickets, nullptr}; pv[0].launch(p, s1);
+          Args q{A[1], W[1], C[1], sh.M, sh.N, sh.K, 0, 0, slabs, tickets, nullptr}; pv[2].launch(q, s2);
+        }
+        CK(hipEventRecord(e1, s1)); CK(hipEventRecord(e2, s2)); CK(hipEventSynchronize(e1)); CK(hipEventSynchronize(e2));
+        float m1, m2; CK(hipEventElapsedTime(&m1, e0, e1)); CK(hipEventElapsedTime(&m2, e0, e2));
+        both = std::min(both, (double)std::max(m1, m2) / INNER);
+      }
+      printf("   %-20s                 | pair %6.1f TF aggregate\n", "64x64 + 128x128", 2 * fl / both * 1e-9);
+    }
+  }
+}
+
 int main(int argc, char** argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 5;
   const char* only = argc > 2 ? argv[2] : nullptr;
+  const bool pair = argc > 1 && !strcmp(argv[1], "pair");
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
   g_cus = prop.multiProcessorCount;
@@ -341,6 +397,13 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&slabs, slab_bytes)); CK(hipMalloc(&tickets, 1 << 20)); CK(hipMemset(tickets, 0, 1 << 20));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   std::vector<float> href, hout;
+  if (pair) {
+    Args p{A[0], W[0], C[0], 50176, 256, 2304, 0, 0, slabs, tickets, nullptr};
+    for (int i = 0; i < 600; ++i) variants[0].launch(p, 0);
+    CK(hipDeviceSynchronize());
+    pair_mode(A, W, C, slabs, tickets);
+    return 0;
+  }
   {   // warm the chip up: ~0.5 s of back-to-back GEMMs
     Args p{A[0], W[0], C[0], 50176, 256, 2304, 0, 0, slabs, tickets, nullptr};
     for (int i = 0; i < 600; ++i) variants[0].launch(p, 0);
