@@ -461,6 +461,33 @@ def test_pick_device_accepts_the_launch_styles_that_do_not_share_a_device():
     bench.launcher_check_devices(2, "gloo", 1)
 
 
+def test_gemm_tune_policy_and_precision_flag_arithmetic(monkeypatch):
+    """ops._shape_tune / _bstats_tune_ok: the per-shape `tune` policy (STIL_GEMM_POLICY, A/B measurements) never moves a launch that
+    carries per-tile statistics to a tile with other statistics rows, the opt-in split-precision flag (+ 100000) survives every
+    decision, and the library's tile-row / variant queries ignore the flags (host logic only: no launch)."""
+    from stil_tta_amd import ops
+    from stil_tta_amd._lib import lib
+    monkeypatch.setattr(ops, "_POLICY", [(2048, 200), (1024, 22)])
+    monkeypatch.setitem(ops.TUNE, "gemm", 0)
+    assert ops._shape_tune(12544, 512, 4608, False, False) == 200          # first rule it meets (sorted by K, descending)
+    assert ops._shape_tune(12544, 512, 1024, False, False) == 22
+    assert ops._shape_tune(12544, 512, 1024, False, True) == 0             # per-tile statistics: 64-row tiles only
+    assert ops._shape_tune(100, 512, 1024, False, False) == 0              # ragged for 128x128
+    assert ops._shape_tune(12544, 512, 512, False, False) == 0 and ops._shape_tune(12544, 512, 4608, True, False) == 0   # below every rule; operand-staging BN
+    monkeypatch.setitem(ops.TUNE, "gemm", ops.B3_FLAG)
+    assert ops._shape_tune(12544, 512, 4608, False, False) == 200 and ops._bstats_tune_ok()
+    monkeypatch.setitem(ops.TUNE, "gemm", ops.B3_FLAG + 44)
+    assert ops._shape_tune(12544, 512, 4608, False, False) == ops.B3_FLAG + 44 and ops._bstats_tune_ok()   # a forced tune wins over the policy
+    monkeypatch.setitem(ops.TUNE, "gemm", 22)
+    assert not ops._bstats_tune_ok()
+    monkeypatch.setitem(ops.TUNE, "gemm", 10000)
+    assert not ops._bstats_tune_ok()                                         # scalar epilogue: no statistics in it
+    L = lib()
+    for t in (0, 11, 44, ops.B3_FLAG, ops.B3_FLAG + 44):
+        assert L.gemm_nt_tile_rows(50176, 256, t) == 64 and L.gemm_nt_variant(50176, 256, t) == 11, t
+    assert L.gemm_nt_tile_rows(50176, 256, 22) == 128 and L.gemm_nt_variant(50176, 256, 21) == 21
+
+
 # ---------------------------------------------------------------- fit-loop host logic (stil_tta_amd/fit.py)
 def test_fit_host_helpers():
     from stil_tta_amd import fit as F
