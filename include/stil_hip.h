@@ -51,12 +51,14 @@ int stil_gemm_nt(const float* A, const float* W, float* C, int M, int N, int K, 
                  const float* scale_var, float var_eps, void* split_ws, size_t split_ws_bytes, int tune, void* stream);
 /* `split_ws` (optional): split-K for grids below one 64x64 workgroup per CU (small per-GPU batches: the step is then a dependent
  *   chain of GEMMs that each leave most of the chip idle).  stil_gemm_nt_split_workspace_bytes(M, N, K, tune) > 0 says the product
- *   would be split; given a workspace of at least that size (256-byte aligned, ZEROED ONCE before its first use -- its first 4 KB
+ *   would be split; given a workspace of at least that size (256-byte aligned, ZEROED ONCE before its first use -- its first 16 KB
  *   hold one arrival ticket per tile, which every launch leaves zero again; products of different shapes may share it -- and not
  *   shared by launches that may run concurrently: one per stream),
  *   the tile's slices write their accumulators to slabs and the slice that draws the last ticket adds them in slice order and runs
  *   the epilogue: deterministic, no workgroup waits.  Without a workspace the product runs unsplit. */
 size_t stil_gemm_nt_split_workspace_bytes(int M, int N, int K, int tune);
+/* measurement hook (tests/tools/split_sweep.py): s > 0 forces s slices wherever a product can be split at all, s <= 0 = the policy */
+int stil_gemm_nt_force_splits(int s);   /* returns the previous setting */
 /* `scale_var` (optional, needs `scale`): the per-column scale is scale[n] / sqrtf(scale_var[n] + var_eps) -- an eval-mode BatchNorm
  *   folded into the conv epilogue straight from (weight, bias, running_mean, running_var): sub = running_mean, scale = weight,
  *   scale_var = running_var, shift = bias, formed exactly as stil_bn_eval_affine forms it (models/resnets.py:112-132 in eval mode). */
@@ -112,6 +114,24 @@ int stil_wgrad_tn(const float* dY, const float* X, float* dW, int M, int N, int 
                   int Kdst, int accumulate, const float* x_bn, float* workspace, size_t workspace_bytes, int tune, void* stream);
 /* `x_bn` (optional): as stil_gemm_nt's a_bn, for the X operand (the raw conv output of the producing layer and its
  * statistics block [4][srcC]). */
+/* DEFERRED reductions (small per-GPU batches under hipGraph replay: the step is ~1000 dependent launches of ~5 us): the _partial
+ * entry points leave only the slab partials ([stil_wgrad_splits][N][K] / [stil_colsum_chunks][N]) in a workspace the CALLER keeps
+ * until it has passed one StilReduceJob per product to stil_reduce_jobs, which finishes all of them in ceil(n / 48) launches -- bit
+ * for bit what stil_wgrad_tn / stil_colsum write.  A colsum is the job {splits = chunks, N = 1, K = N, Cin = N, taps = 1, Kdst = N}.
+ * Jobs of one call must have distinct `dst`.  `jobs` is HOST memory (the jobs travel as kernel arguments). */
+typedef struct StilReduceJob {
+  const float* P; float* dst;
+  int splits, N, K, Cin, taps, Kdst, accumulate;
+  float scale;
+} StilReduceJob;
+int stil_reduce_job_bytes(void);
+int stil_wgrad_splits(int M, int N, int K, int tune);
+int stil_wgrad_tn_partial(const float* dY, const float* X, int M, int N, int K, int ldy, int ldx,
+                          int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad,
+                          const float* x_bn, float* workspace, size_t workspace_bytes, int tune, void* stream);
+int stil_colsum_chunks(int M);
+int stil_colsum_partial(const float* X, int M, int N, int ld, float* workspace, size_t workspace_bytes, void* stream);
+int stil_reduce_jobs(const void* jobs, int njobs, void* stream);
 
 /* out[n] (+)= scale * sum_m X[m,n]   (bias gradients) */
 size_t stil_colsum_workspace_bytes(int M, int N);

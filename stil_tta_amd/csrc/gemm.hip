@@ -667,26 +667,31 @@ void gemm_nt_kernel(GemmNTArgs p) {
 
   if constexpr (TM * TN == 1) {
     if (p.splits > 1) {
-      // The hand-off of cdna_hip_programming.md (split-K, counter form): plain slab stores -> every wave drains its stores ->
-      // workgroup barrier -> ONE lane: agent-scope release, drain, relaxed agent ticket.  The workgroup that draws the last ticket:
-      // ONE lane agent-scope acquire, drain, workgroup barrier, then every wave reads all slabs with plain loads.
+      // The hand-off of cdna_hip_programming.md (split-K, counter form) with WRITE-THROUGH slabs: every slice stores its accumulators
+      // with 16-byte sc1 stores (they leave the XCD's L2: no release fence, which would write back every dirty line of that L2 --
+      // the other workgroups' output tiles -- once per slice: measured 40 us on a 45 us product of 784 tiles cut in two) -> every
+      // wave drains its stores -> workgroup barrier -> ONE lane draws a relaxed agent-scope ticket.  The workgroup that draws the
+      // last ticket reads all slabs with sc1 loads (every load of them: they bypass this CU's L1, so no acquire either).
       const long tile = wg;
-      float* slab = p.split_slabs + (tile * p.splits + split) * 4096;
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      const float* tbase = p.split_slabs + tile * p.splits * 4096;    // block-uniform
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tbase);
+      const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)tbase >> 32));
+      const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | lo), 0, p.splits * 16384, 0x00020000);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) slab[r * 256 + tid] = acc[0][0][r];     // 256 consecutive floats per register: coalesced
+      for (int q = 0; q < 4; ++q) {   // lane tid holds floats [q][tid][0..3] of its slice's slab
+        u32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __float_as_uint(acc[0][0][q * 4 + e]);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (split * 4096 + q * 1024 + tid * 4) * 4, 0, 16);   // aux 16 = sc1
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       int* flag = reinterpret_cast<int*>(lds);    // the operand buffers are free; the ONE LDS array of the kernel
       if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int old = __hip_atomic_fetch_add(p.split_tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = old == p.splits - 1;
-        if (last) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __hip_atomic_store(p.split_tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // everybody has arrived: ready for the next launch
-        }
+        if (last) __hip_atomic_store(p.split_tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // everybody has arrived: ready for the next launch
         flag[0] = last;
       }
       __syncthreads();
@@ -695,13 +700,16 @@ void gemm_nt_kernel(GemmNTArgs p) {
       if (!last) return;        // block-uniform
       // slice order, in DOUBLE, rounded to fp32 once: the same sum on every run, and each slice's partial enters exactly (the
       // split product carries less rounding noise than the unsplit chain of K / 64 partial sums it replaces)
-      const float* s0 = p.split_slabs + tile * p.splits * 4096;
       double dsum[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) dsum[r] = 0.0;
       for (int s_ = 0; s_ < p.splits; ++s_) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dsum[r] += (double)s0[(long)s_ * 4096 + r * 256 + tid];
+        for (int q = 0; q < 4; ++q) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (s_ * 4096 + q * 1024 + tid * 4) * 4, 0, 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dsum[q * 4 + e] += (double)__uint_as_float(v[e]);
+        }
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[0][0][r] = (float)dsum[r];
@@ -1202,6 +1210,119 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------
+// DEFERRED reductions (small per-GPU batches under hipGraph replay, where the step is ~1000 dependent launches of ~5 us each):
+// stil_wgrad_tn_partial / stil_colsum_partial leave only their slab partials; the caller collects one StilReduceJob per product
+// and stil_reduce_jobs finishes ALL of them in ceil(n / 48) launches (the jobs travel as kernel arguments: no device table, nothing
+// to keep alive under graph replay) instead of one wgrad_reduce / colsum_final launch per product (137 of a step's 1055 launches).
+// Same arithmetic, bit for bit, as the immediate kernels: the vector body is wgrad_reduce4_kernel's (= colsum_final_kernel's
+// chunk_reduce<8>: lane l adds slabs l, l + 8, ..., the 8 lane sums are added in lane order), the scalar body wgrad_reduce_kernel's.
+#define STIL_REDUCE_BATCH 48
+struct ReduceJob {             // include/stil_hip.h StilReduceJob
+  const float* P;              // [splits][N][K] partials
+  float* dst;                  // dW: [N, Kdst] (taps == 1) or (N, Cin, KH, KW) (taps > 1)
+  int splits, N, K, Cin, taps, Kdst, accumulate;
+  float scale;
+};
+struct ReduceBatch {
+  int n;
+  int first_block[STIL_REDUCE_BATCH + 1];
+  ReduceJob job[STIL_REDUCE_BATCH];
+};
+static inline bool reduce_job_vec(const ReduceJob& j) {
+  return j.K % 4 == 0 && (j.taps == 1 || j.Cin % 4 == 0) && ((uintptr_t)j.P % 16) == 0;
+}
+static inline int reduce_job_blocks(const ReduceJob& j) {
+  const long total = (long)j.N * j.K;
+  return reduce_job_vec(j) ? cdiv(total / 4, 256) : cdiv(total, 256);
+}
+// Vector body: ONE thread per four consecutive k with eight running sums t[l] = P[l] + P[l + 8] + ... added in order at the end --
+// exactly the association of wgrad_reduce4_kernel's eight row lanes (and of chunk_reduce<8>), so the bits agree, but with eight
+// independent loads in flight per thread and no LDS: the deferred slabs are read cold from HBM (0.5-1.5 GB per step), where the
+// lane form (one load in flight in 1/8 of the threads when a product has few slabs) managed 0.5 TB/s.
+__global__ __launch_bounds__(256) void reduce_jobs_kernel(ReduceBatch b) {
+  int ji = 0;
+  while (ji + 1 < b.n && (int)blockIdx.x >= b.first_block[ji + 1]) ++ji;     // block-uniform (scalar loads of kernel arguments)
+  const ReduceJob& j = b.job[ji];
+  const int lb = blockIdx.x - b.first_block[ji];
+  const long total = (long)j.N * j.K;
+  const bool vec = j.K % 4 == 0 && (j.taps == 1 || j.Cin % 4 == 0) && ((uintptr_t)j.P % 16) == 0;
+  if (vec) {
+    const long idx = ((long)lb * 256 + threadIdx.x) * 4;
+    if (idx >= total) return;
+    float4 t[8];
+#pragma unroll
+    for (int l = 0; l < 8; ++l) t[l] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* src = j.P + idx;
+    int zz = 0;
+    for (; zz + 8 <= j.splits; zz += 8) {
+#pragma unroll
+      for (int l = 0; l < 8; ++l) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (long)(zz + l) * total);
+        t[l].x += v.x; t[l].y += v.y; t[l].z += v.z; t[l].w += v.w;
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < 8; ++l)
+      if (zz + l < j.splits) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (long)(zz + l) * total);
+        t[l].x += v.x; t[l].y += v.y; t[l].z += v.z; t[l].w += v.w;
+      }
+    float4 s = t[0];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) { s.x += t[q].x; s.y += t[q].y; s.z += t[q].z; s.w += t[q].w; }
+    const int n = (int)(idx / j.K), k = (int)(idx - (long)n * j.K);
+    const float sv[4] = {s.x * j.scale, s.y * j.scale, s.z * j.scale, s.w * j.scale};
+    if (j.taps == 1 && k + 3 < j.Kdst && j.Kdst % 4 == 0 && ((uintptr_t)j.dst % 16) == 0) {    // whole quad inside the row, 16-byte aligned
+      float4* o = reinterpret_cast<float4*>(j.dst + (long)n * j.Kdst + k);
+      float4 r = make_float4(sv[0], sv[1], sv[2], sv[3]);
+      if (j.accumulate) { const float4 c = *o; r.x = c.x + sv[0]; r.y = c.y + sv[1]; r.z = c.z + sv[2]; r.w = c.w + sv[3]; }
+      *o = r;
+      return;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int dst = k + e;
+      if (j.taps > 1) { const int tap = k / j.Cin, c = k - tap * j.Cin; dst = (c + e) * j.taps + tap; }   // c .. c + 3 stay inside the tap
+      if (dst < j.Kdst) { const long o = (long)n * j.Kdst + dst; j.dst[o] = j.accumulate ? j.dst[o] + sv[e] : sv[e]; }
+    }
+  } else {
+    const long idx = (long)lb * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int n = (int)(idx / j.K), k = (int)(idx - (long)n * j.K);
+    float s = 0.f;
+    for (int zz = 0; zz < j.splits; ++zz) s += j.P[(long)zz * total + idx];
+    s *= j.scale;
+    int dst = k;
+    if (j.taps > 1) { const int tap = k / j.Cin, c = k - tap * j.Cin; dst = c * j.taps + tap; }
+    if (dst >= j.Kdst) return;
+    const long o = (long)n * j.Kdst + dst;
+    j.dst[o] = j.accumulate ? j.dst[o] + s : s;
+  }
+}
+extern "C" int stil_reduce_job_bytes(void) { return (int)sizeof(ReduceJob); }
+extern "C" int stil_reduce_jobs(const void* jobs_host, int njobs, void* stream) {
+  STIL_REQUIRE(jobs_host && njobs > 0, "stil_reduce_jobs: null pointer or no jobs");
+  const ReduceJob* jobs = (const ReduceJob*)jobs_host;
+  for (int j0 = 0; j0 < njobs; j0 += STIL_REDUCE_BATCH) {
+    ReduceBatch b;
+    b.n = njobs - j0 < STIL_REDUCE_BATCH ? njobs - j0 : STIL_REDUCE_BATCH;
+    int nb = 0;
+    for (int i = 0; i < b.n; ++i) {
+      const ReduceJob& j = jobs[j0 + i];
+      STIL_REQUIRE(j.P && j.dst && j.splits > 0 && j.N > 0 && j.K > 0 && j.taps > 0 && (j.taps == 1 || j.Cin * j.taps == j.K),
+                   "stil_reduce_jobs: bad job %d", j0 + i);
+      b.job[i] = j;
+      b.first_block[i] = nb;
+      nb += reduce_job_blocks(j);
+    }
+    for (int i = b.n; i <= STIL_REDUCE_BATCH; ++i) b.first_block[i] = nb;
+    hipLaunchKernelGGL(reduce_jobs_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, b);
+    STIL_LAUNCH_CHECK();
+  }
+  return STIL_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 static int check_geom(const ConvGeom& g, int vec_required) {
   if (g.KH * g.KW > 1 && (g.C % 16) != 0) {
     stil_set_error("implicit-GEMM conv needs Cin %% 16 == 0 (got %d)", g.C);
@@ -1297,16 +1418,34 @@ extern "C" int stil_gemm_nt_config(const float* A, const float* W, int M, int N,
   return nt_config(A, W, M, N, K, lda, ldb, srcC, KH, KW, plain, a_bn, tune, true);
 }
 
-// split-K policy: only 64x64 tiles whose grid would leave most CUs idle (fewer than one workgroup per CU) and whose reduction is
-// long enough to cut: at least 4 k-tiles (of 32) per slice, at most 16 slices, aiming at >= 512 workgroups.
+// split-K policy (64x64 tiles only), from tests/tools/split_sweep.py's table of what a per-GPU batch of 16-32 samples launches
+// (profiles/r05_split_sweep.txt; with write-through slabs a slice costs ~1 us, so the question is only whether the grid leaves CUs
+// idle or a last partial round of workgroups).  Grids below one workgroup per CU: slices of >= 4 k-tiles (of 32) aiming at >= 512
+// workgroups (>= 1536 when the reduction is long, >= 64 k-tiles).  Grids of 256-1535 tiles: only long reductions (>= 36 k-tiles),
+// slices of >= 12 k-tiles aiming at >= 1536 workgroups (one and a half rounds of the chip's 1024 resident workgroups).  At most
+// 8 slices: the last arrival reads them all.  B = 256 launches none of these shapes except the heads' M = 256 products.
+// stil_gemm_nt_force_splits(s): measurement hook (tests/tools/split_sweep.py), s > 0 forces s slices wherever a product can be
+// split at all (64x64 tiles, K >= 256, at most NT_SPLIT_MAX_TILES tiles, >= 2 k-tiles per slice); s <= 0 = the policy.
+#define NT_SPLIT_MAX_TILES 4096
+static int g_force_splits = 0;
+extern "C" int stil_gemm_nt_force_splits(int s) { const int old = g_force_splits; g_force_splits = s; return old; }
 static int nt_splits(int M, int N, int K, int tune) {
   if (stil_gemm_nt_variant(M, N, tune) != 11) return 1;
   const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
-  if (tiles >= 256 || K < 256) return 1;
-  int s = cdiv(512, tiles);
-  const int maxs = K / 128;
+  if (g_force_splits > 0) {
+    if (tiles > NT_SPLIT_MAX_TILES || K < 256) return 1;
+    int s = g_force_splits;
+    if (s > K / 64) s = K / 64;
+    return s < 2 ? 1 : s;
+  }
+  if (K < 256 || tiles >= 1536) return 1;
+  const int kt = K / 32;
+  int maxs, target;
+  if (tiles < 256) { maxs = kt / 4; target = kt >= 64 ? 1536 : 512; }
+  else { if (kt < 36) return 1; maxs = kt / 12; target = 1536; }
+  int s = cdiv(target, tiles);
   if (s > maxs) s = maxs;
-  if (s > 16) s = 16;
+  if (s > 8) s = 8;
   return s < 2 ? 1 : s;
 }
 // column-panel width (in 64-column tiles) of the tile order, 0 = row-tile major.  Panels pay when W (N x K floats) does not fit an
@@ -1329,11 +1468,11 @@ static int nt_panel(int M, int N, int K) {
 }
 
 // bytes of the split-K workspace stil_gemm_nt wants for this product (0: the product is not split).  Layout: a FIXED ticket
-// region of NT_SPLIT_TICKET_BYTES (one int per tile; split products have fewer than 256 tiles) then [tiles][splits][64*64] float
+// region of NT_SPLIT_TICKET_BYTES (one int per tile; split products have at most NT_SPLIT_MAX_TILES tiles) then [tiles][splits][64*64] float
 // slabs -- fixed, so that one workspace can serve products of different shapes: no product's slabs ever overlap another's tickets.
 // The caller zeroes it ONCE (the tickets); every launch leaves the tickets zero again.  One workspace per stream: launches that
 // may run concurrently must not share one.
-#define NT_SPLIT_TICKET_BYTES 4096
+#define NT_SPLIT_TICKET_BYTES (4 * NT_SPLIT_MAX_TILES)
 extern "C" size_t stil_gemm_nt_split_workspace_bytes(int M, int N, int K, int tune) {
   const int s = nt_splits(M, N, K, tune % 10000);
   if (s <= 1) return 0;
@@ -1507,10 +1646,11 @@ extern "C" size_t stil_wgrad_workspace_bytes(int M, int N, int K, int tune) {
 }
 
 // dW (+)= dY^T . Xgather ; dW laid out [N, Kdst] (taps==1) or (N, Cin, KH, KW) (taps>1)
-extern "C" int stil_wgrad_tn(const float* dY, const float* X, float* dW, int M, int N, int K, int ldy, int ldx,
+extern "C" int stil_wgrad_splits(int M, int N, int K, int tune) { return wgrad_splits(M, N, K, tune); }
+static int wgrad_tn_impl(const float* dY, const float* X, float* dW, int M, int N, int K, int ldy, int ldx,
                              int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad,
                              int Kdst, int accumulate, const float* x_bn, float* workspace, size_t workspace_bytes, int tune, void* stream) {
-  STIL_REQUIRE(dY && X && dW && workspace, "stil_wgrad_tn: null pointer");
+  STIL_REQUIRE(dY && X && workspace, "stil_wgrad_tn: null pointer");
   STIL_REQUIRE(tune == 0 || tune == 11 || tune == 22, "stil_wgrad_tn: bad tune %d", tune);
   STIL_REQUIRE(KH * KW * srcC == K, "stil_wgrad_tn: K=%d != KH*KW*C=%d", K, KH * KW * srcC);
   STIL_REQUIRE(M % (OH * OW) == 0, "stil_wgrad_tn: M=%d not a multiple of OH*OW", M);
@@ -1546,6 +1686,7 @@ extern "C" int stil_wgrad_tn(const float* dY, const float* X, float* dW, int M, 
     else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, false>), grid, dim3(256), 0, s, p);
   }
   STIL_LAUNCH_CHECK();
+  if (!dW) return STIL_OK;     // stil_wgrad_tn_partial: the caller reduces the slabs later (stil_reduce_jobs)
   long total = (long)N * K;
   int taps = KH * KW;
   if (K % 4 == 0 && (taps == 1 || srcC % 4 == 0) && ((uintptr_t)workspace % 16) == 0)
@@ -1558,20 +1699,46 @@ extern "C" int stil_wgrad_tn(const float* dY, const float* X, float* dW, int M, 
   return STIL_OK;
 }
 
+extern "C" int stil_wgrad_tn(const float* dY, const float* X, float* dW, int M, int N, int K, int ldy, int ldx,
+                             int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad,
+                             int Kdst, int accumulate, const float* x_bn, float* workspace, size_t workspace_bytes, int tune, void* stream) {
+  STIL_REQUIRE(dW, "stil_wgrad_tn: null pointer");
+  return wgrad_tn_impl(dY, X, dW, M, N, K, ldy, ldx, srcH, srcW, srcC, OH, OW, KH, KW, stride, pad, Kdst, accumulate, x_bn, workspace,
+                       workspace_bytes, tune, stream);
+}
+// the slab partials only: workspace = [stil_wgrad_splits(M, N, K, tune)][N][K]; finish with a StilReduceJob (stil_reduce_jobs)
+extern "C" int stil_wgrad_tn_partial(const float* dY, const float* X, int M, int N, int K, int ldy, int ldx,
+                                     int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad,
+                                     const float* x_bn, float* workspace, size_t workspace_bytes, int tune, void* stream) {
+  return wgrad_tn_impl(dY, X, nullptr, M, N, K, ldy, ldx, srcH, srcW, srcC, OH, OW, KH, KW, stride, pad, K, 0, x_bn, workspace,
+                       workspace_bytes, tune, stream);
+}
+
 extern "C" size_t stil_colsum_workspace_bytes(int M, int N) {
   int rpc = 128;
   return (size_t)cdiv(M, rpc) * N * sizeof(float);
 }
 
-extern "C" int stil_colsum(const float* X, float* out, int M, int N, int ld, int accumulate, float scale,
-                           float* workspace, size_t workspace_bytes, void* stream) {
-  STIL_REQUIRE(X && out && workspace && M > 0 && N > 0, "stil_colsum: null pointer or empty shape");
+static int colsum_impl(const float* X, float* out, int M, int N, int ld, int accumulate, float scale,
+                       float* workspace, size_t workspace_bytes, void* stream) {
+  STIL_REQUIRE(X && workspace && M > 0 && N > 0, "stil_colsum: null pointer or empty shape");
   int rpc = 128, nch = cdiv(M, rpc);
   STIL_REQUIRE(workspace_bytes >= (size_t)nch * N * sizeof(float), "stil_colsum: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), nch), dim3(256), 0, s, X, workspace, M, N, ld, rpc);
   STIL_LAUNCH_CHECK();
+  if (!out) return STIL_OK;    // stil_colsum_partial
   hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 32)), dim3(256), 0, s, workspace, out, nch, N, accumulate, scale);
   STIL_LAUNCH_CHECK();
   return STIL_OK;
+}
+extern "C" int stil_colsum(const float* X, float* out, int M, int N, int ld, int accumulate, float scale,
+                           float* workspace, size_t workspace_bytes, void* stream) {
+  STIL_REQUIRE(out, "stil_colsum: null pointer or empty shape");
+  return colsum_impl(X, out, M, N, ld, accumulate, scale, workspace, workspace_bytes, stream);
+}
+// the per-chunk partials only: workspace = [stil_colsum_chunks(M)][N]; finish with a StilReduceJob {splits = chunks, N = 1, K = N}
+extern "C" int stil_colsum_chunks(int M) { return cdiv(M, 128); }
+extern "C" int stil_colsum_partial(const float* X, int M, int N, int ld, float* workspace, size_t workspace_bytes, void* stream) {
+  return colsum_impl(X, nullptr, M, N, ld, 0, 1.f, workspace, workspace_bytes, stream);
 }

@@ -184,11 +184,11 @@ def synthetic_batch(field_lengths, num_classes: int, B: int, img_size: int, seed
 
 
 def wants_graph(batch: int, img_size: int) -> bool:
-    """Is a step of this per-GPU size bound by its ~1100 dependent launches rather than by the chip?  Measured (profiles/r04z_*,
-    r05_*): the cardiac share of 16 samples per GPU at 128 px runs 21.5-23.5 ms eager and 13.6-15.8 ms replayed; B = 64 at 128 px
-    and B = 32 at 224 px are equal either way; from there on eager launches win (B = 256: 130 vs 138 ms).  The boundary is put at
-    half a million pixels per step."""
-    return batch * img_size * img_size <= 524288
+    """Is a step of this per-GPU size bound by its ~1100 dependent launches rather than by the chip?  Measured (profiles/r05u_*,
+    one box, graph replay with deferred gradient reductions): the cardiac share of 16 samples per GPU at 128 px runs 21.5-23.5 ms
+    eager and 11.8 ms replayed; B = 64 at 128 px 23.4 eager / 22.8 replayed; B = 32 at 224 px is equal either way (24.0-24.8 /
+    24.4); from there on eager launches win (B = 256: 119 vs 138 ms).  The boundary is put at a million pixels per step."""
+    return batch * img_size * img_size <= 1048576
 
 
 class GraphedTrainStep:
@@ -227,16 +227,19 @@ class GraphedTrainStep:
         return [(t, t.clone()) for t in tensors]
 
     def _capture(self):
+        from . import ops
         snap = self._snapshot()  # warm-up steps are real optimisation steps: their effect is rolled back below
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):  # eager warm-up on a side stream (allocator + lazy one-time setup), as PyTorch requires
+        # gradient slab reductions are deferred to one multi-job launch per step (ops._DeferredReduce): in the warm-up too, which
+        # sizes the arena the capture then bakes in
+        with torch.cuda.stream(side), ops.deferring():  # eager warm-up on a side stream (allocator + lazy one-time setup), as PyTorch requires
             for _ in range(self.warmup):
                 train_step(self.model, self.optimizer, self.static)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):  # records the step; nothing executes until replay()
+        with torch.cuda.graph(self.graph), ops.deferring():  # records the step; nothing executes until replay()
             self.loss = train_step(self.model, self.optimizer, self.static)
         self._key = self._signature()
         for t, c in snap:

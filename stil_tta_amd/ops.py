@@ -74,12 +74,13 @@ class _SplitWorkspace(_Workspace):
 
 
 _split_ws = _SplitWorkspace()
-# Split-K of the NT products whose grid is below one workgroup per CU (include/stil_hip.h `split_ws`): AUTOMATIC -- the library
-# splits only products of fewer than 256 tiles with K >= 256 (gemm.hip nt_splits), i.e. what a per-GPU batch of 16-64 samples
-# launches (cardiac share of 16 samples per GPU: 16.6 -> 13.8 ms per step under graph replay) and, at B = 256, only the heads'
-# M = 256 products (step unchanged: 2117.0 / 2116.4 samples/s, profiles/r04_experiments.txt 9).  Round 4 kept it opt-in because it
-# re-rolls the rounding of every small product, which moved projector_imaging.bias across its bar; that gradient's noise had
-# another cause (csrc/loss.hip, round 5) and sits at 0.1-0.4 of its bar now.  STIL_SPLITK=0 turns it off.
+# Split-K of the NT products whose grid leaves CUs idle (include/stil_hip.h `split_ws`): AUTOMATIC -- the library splits grids below
+# one 64x64 workgroup per CU with K >= 256, and grids of 256-1535 tiles with K >= 1152 (gemm.hip nt_splits, from tests/tools/
+# split_sweep.py), i.e. what a per-GPU batch of 16-64 samples launches (cardiac share of 16 samples per GPU under graph replay:
+# 16.6 ms unsplit, 13.6 ms with release/acquire slabs, 12.1 ms with write-through slabs and this policy) and, at B = 256, only
+# the heads' M = 256 products (step unchanged).  Round 4 kept it opt-in because it re-rolls the rounding of every small product,
+# which moved projector_imaging.bias across its bar; that gradient's noise had another cause (csrc/loss.hip, round 5) and sits at
+# 0.1-0.4 of its bar now.  STIL_SPLITK=0 turns it off.
 _SPLITK = __import__("os").environ.get("STIL_SPLITK", "1") != "0"
 
 # per-call tuning arguments of stil_gemm_nt / stil_wgrad_tn (include/stil_hip.h); 0 = automatic.  Only the measurement
@@ -137,7 +138,8 @@ _side = _SideStream()
 
 
 def join_side():
-    """Make the current stream wait for every side-stream launch issued so far."""
+    """Make the current stream wait for every side-stream launch issued so far (deferred gradient reductions included)."""
+    _defer.flush()
     for st in _side.streams.values():
         torch.cuda.current_stream(st.device).wait_stream(st)
     _side.retire(everything=True)   # the current stream is now ordered after every side-stream read
@@ -196,12 +198,92 @@ def _grad_into(param: torch.Tensor, writer):
     (returns None for autograd); plain tensors get a fresh gradient tensor (returned)."""
     slot = getattr(param, "_gslot", None)
     if slot is not None:
-        writer(slot, 1)
+        writer(slot, 1, True)
         _touch(param)
         return None
     g = torch.empty_like(param)
-    writer(g, 0)
+    writer(g, 0, False)
     return g
+
+
+# ------------------------------------------------------------------------------------------ deferred reductions
+class _DeferredReduce:
+    """Small per-GPU batches under hipGraph replay are ~1000 dependent launches of ~5 us: the slab reduction that follows every
+    weight-gradient GEMM and every bias column sum (137 launches of the cardiac step's 1055) is DEFERRED -- the products leave their
+    partials in an arena, one StilReduceJob each is collected, and flush() (join_side(): before anything reads the gradient slab)
+    finishes them all in ceil(n / 48) launches, bit for bit what the immediate kernels write (include/stil_hip.h).
+    Only gradients that go to the slab (+=) are deferred, never under a GradExchange (it all-reduces buckets as they finish).
+    STIL_REDUCE_DEFER = auto (default: inside driver.GraphedTrainStep's warm-up and capture) | 1 (always) | 0 (never)."""
+    _JOB = __import__("struct").Struct("<QQ7if")
+
+    def __init__(self):
+        self.mode = __import__("os").environ.get("STIL_REDUCE_DEFER", "auto")
+        self.forced = 0                 # > 0 inside `deferring()`
+        self.ws = _Workspace()          # the arena's backing buffer, one per (device, stream), pinned under capture
+        self.st = {}                    # key -> dict(stream, size, off, jobs, dsts)
+        self.high = {}                  # device -> largest arena use so far (a new stream's arena starts at 1.25 x that:
+                                        # GraphedTrainStep warms up on one stream and captures on another)
+
+    def active(self) -> bool:
+        if _exchange is not None or self.mode == "0":
+            return False
+        return self.mode == "1" or self.forced > 0
+
+    def _state(self, device):
+        st = torch.cuda.current_stream(device)
+        key = (device, st.stream_id, st.cuda_stream)
+        d = self.st.get(key)
+        if d is None:
+            d = self.st[key] = dict(stream=st, device=device, size=max(256 << 20, int(1.25 * self.high.get(device, 0))), off=0, jobs=[], dsts=set())
+        return d
+
+    def alloc(self, nbytes: int, device) -> int:
+        """-> device address of `nbytes` (256-byte aligned) that stay valid until this stream's next flush"""
+        d = self._state(device)
+        n = (int(nbytes) + 255) & ~255
+        if d["off"] + n > d["size"]:
+            self._flush_one(d)                     # the pending partials are consumed before their memory is reused / regrown
+            d["size"] = max(d["size"], 2 * n, int(1.25 * self.high.get(device, 0)))
+        buf = self.ws.get(d["size"], device)
+        assert buf.numel() >= d["size"]
+        a = buf.data_ptr() + d["off"]
+        a += (-a) % 256
+        d["off"] = a - buf.data_ptr() + n
+        self.high[device] = max(self.high.get(device, 0), d["off"])
+        return a
+
+    def add(self, device, P: int, dst: torch.Tensor, splits, N, K, Cin, taps, Kdst, accumulate, scale):
+        d = self._state(device)
+        if dst.data_ptr() in d["dsts"]:            # two contributions to one slot: in order
+            self._flush_one(d)
+        d["dsts"].add(dst.data_ptr())
+        d["jobs"].append(self._JOB.pack(P, dst.data_ptr(), splits, N, K, Cin, taps, Kdst, accumulate, float(scale)))
+
+    def _flush_one(self, d):
+        if d["jobs"]:
+            L = lib()
+            assert L.reduce_job_bytes() == self._JOB.size, "StilReduceJob layout changed"
+            blob = b"".join(d["jobs"])
+            with torch.cuda.stream(d["stream"]):
+                L.reduce_jobs(blob, len(d["jobs"]), d["stream"].cuda_stream)
+        d["jobs"], d["dsts"], d["off"] = [], set(), 0
+
+    def flush(self):
+        for d in self.st.values():
+            self._flush_one(d)
+
+
+_defer = _DeferredReduce()
+
+
+class deferring:
+    """with ops.deferring(): gradient reductions of the enclosed steps are deferred (driver.GraphedTrainStep's warm-up and capture)"""
+
+    def __enter__(self):
+        _defer.forced += 1
+
+    def __exit__(self, *exc):
+        _defer.forced -= 1
 
 
 # ------------------------------------------------------------------------------------------ raw wrappers
@@ -273,16 +355,22 @@ def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None,
     return out
 
 
-def wgrad_tn(dY, X, dW, M, N, K, *, ldy=None, ldx=None, geom=None, Kdst=None, accumulate=0, x_bn=None):
+def wgrad_tn(dY, X, dW, M, N, K, *, ldy=None, ldx=None, geom=None, Kdst=None, accumulate=0, x_bn=None, slot=False):
+    """`slot`: dW is a view of the gradient slab -- its slab reduction may be deferred to the next join_side() (_DeferredReduce)"""
     if geom is None:
         geom = (1, 1, K, 1, 1, 1, 1, 1, 0)
     ldy = N if ldy is None else ldy
     ldx = geom[2] if ldx is None else ldx
     Kdst = K if Kdst is None else Kdst
-    nb = lib().wgrad_workspace_bytes(M, N, K, TUNE["wgrad"])
-    w = _ws.get(nb, dY.device)
     L = lib()
+    nb = L.wgrad_workspace_bytes(M, N, K, TUNE["wgrad"])
     meta = (0, 2.0 * M * N * K, (M, N, K, geom[5], geom[7], 2)) if L._prof is not None else None
+    if slot and _defer.active():
+        a = _defer.alloc(nb, dY.device)
+        L.wgrad_tn_partial(_p(dY), _p(X), M, N, K, ldy, ldx, *geom, _p(x_bn), a, nb, TUNE["wgrad"], _stream(), meta=meta)
+        _defer.add(dY.device, a, dW, L.wgrad_splits(M, N, K, TUNE["wgrad"]), N, K, geom[2], geom[5] * geom[6], Kdst, accumulate, 1.0)
+        return
+    w = _ws.get(nb, dY.device)
     L.wgrad_tn(_p(dY), _p(X), _p(dW), M, N, K, ldy, ldx, *geom, Kdst, accumulate, _p(x_bn), _p(w), nb, TUNE["wgrad"], _stream(), meta=meta)
 
 
@@ -297,13 +385,13 @@ def wgrad_param(param, dY, X, M, N, K, **kw):
     slot = getattr(param, "_gslot", None)
     side = side_stream(dY.device) if (slot is not None and _WGRAD_SIDE) else None
     if side is None:
-        return _grad_into(param, lambda dst, acc: wgrad_tn(dY, X, dst, M, N, K, accumulate=acc, **kw))
+        return _grad_into(param, lambda dst, acc, slot_: wgrad_tn(dY, X, dst, M, N, K, accumulate=acc, slot=slot_, **kw))
     main = torch.cuda.current_stream()
     _side.retire()
     if main != side:
         side.wait_stream(main)
     with torch.cuda.stream(side):
-        wgrad_tn(dY, X, slot, M, N, K, accumulate=1, **kw)
+        wgrad_tn(dY, X, slot, M, N, K, accumulate=1, slot=True, **kw)
         if main != side:
             ev = torch.cuda.Event()
             ev.record(side)
@@ -317,10 +405,16 @@ def _prof_active():
     return L._prof is not None and L._prof_single  # single-stream profiling: keep every launch on the caller's stream
 
 
-def colsum(X, out, M, N, *, ld=None, accumulate=0, scale=1.0):
-    nb = lib().colsum_workspace_bytes(M, N)
+def colsum(X, out, M, N, *, ld=None, accumulate=0, scale=1.0, slot=False):
+    L = lib()
+    nb = L.colsum_workspace_bytes(M, N)
+    if slot and _defer.active():    # see wgrad_tn
+        a = _defer.alloc(nb, X.device)
+        L.colsum_partial(_p(X), M, N, N if ld is None else ld, a, nb, _stream())
+        _defer.add(X.device, a, out, L.colsum_chunks(M), 1, N, N, 1, N, accumulate, scale)
+        return
     w = _ws.get(nb, X.device)
-    lib().colsum(_p(X), _p(out), M, N, N if ld is None else ld, accumulate, float(scale), _p(w), nb, _stream())
+    L.colsum(_p(X), _p(out), M, N, N if ld is None else ld, accumulate, float(scale), _p(w), nb, _stream())
 
 
 def transpose(x2d):
@@ -386,7 +480,7 @@ class LinearFn(torch.autograd.Function):
         dw = wgrad_param(weight, g, x2, M, N, K) if ctx.needs_input_grad[1] else None
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _grad_into(bias, lambda dst, acc: colsum(g, dst, M, N, accumulate=acc))
+            db = _grad_into(bias, lambda dst, acc, slot_: colsum(g, dst, M, N, accumulate=acc, slot=slot_))
         dres = gy if (ctx.has_resid and ctx.needs_input_grad[4]) else None   # the residual branch: identity
         return dx, dw, db, None, dres
 

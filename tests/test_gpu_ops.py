@@ -1047,3 +1047,56 @@ def test_gemm_split_k_is_the_unsplit_product_and_deterministic(ops, M, N, K, con
         close(outs["b"], ops.gemm_nt(A2, W, M, N, K, geom=geom, bias=b, resid=R, act=1), tol=0.0, name="second stream")
     finally:
         ops._SPLITK = default_split
+
+
+def test_deferred_gradient_reductions_equal_the_immediate_ones_bit_for_bit(ops):
+    """ops._DeferredReduce (graph-replayed small batches): weight-gradient / bias-sum partials stay in the arena and ONE multi-job
+    launch (stil_reduce_jobs) finishes them at join_side() -- the same bits as stil_wgrad_tn / stil_colsum, for convolution layouts
+    (taps > 1), truncated rows (Kdst < K: the padded stem), unaligned shapes (scalar body), two contributions to one slot (flushed in
+    order), more jobs than one launch carries (48) and an arena too small for the step (flush + regrow in the middle)."""
+    g = torch.Generator().manual_seed(5)
+    cases = []    # (dY, X, M, N, K, kwargs, dW shape)
+    for (Cin, Cout, k, H) in ((32, 64, 3, 9), (64, 48, 1, 14), (16, 32, 3, 7), (128, 256, 1, 4)):
+        Nb = 3
+        x = torch.randn(Nb, H, H, Cin, generator=g).cuda()
+        M = Nb * H * H
+        dy = torch.randn(M, Cout, generator=g).cuda()
+        kw = dict(geom=(H, H, Cin, H, H, k, k, 1, k // 2)) if k > 1 else {}
+        cases.append((dy, x.view(M, Cin) if k == 1 else x, M, Cout, k * k * Cin, kw, (Cout, Cin, k, k) if k > 1 else (Cout, Cin)))
+    xs = torch.randn(700, 160, generator=g).cuda(); dys = torch.randn(700, 64, generator=g).cuda()
+    cases.append((dys, xs, 700, 64, 160, dict(Kdst=147), (64, 147)))                       # padded stem: only 147 of 160 columns exist
+    xu = torch.randn(300, 37, generator=g).cuda(); dyu = torch.randn(300, 10, generator=g).cuda()
+    cases.append((dyu, xu, 300, 10, 37, {}, (10, 37)))                                     # K % 4 != 0: scalar body
+    cases = cases * 9                                                                      # 54 weight jobs + 54 bias jobs > 2 x 48
+    bias_in = [c[0] for c in cases]
+
+    def run(deferred):
+        outs = [torch.full(c[6], 0.5, device="cuda") for c in cases]
+        bouts = [torch.full((c[3],), -0.25, device="cuda") for c in cases]
+        twice = torch.zeros(cases[0][6], device="cuda")
+        for c, o, b, bi in zip(cases, outs, bouts, bias_in):
+            ops.wgrad_tn(c[0], c[1], o, c[2], c[3], c[4], accumulate=1, slot=True, **c[5])
+            ops.colsum(bi, b, c[2], c[3], accumulate=1, scale=0.5, slot=True)
+        c = cases[0]
+        for _ in range(3):      # three contributions to ONE destination
+            ops.wgrad_tn(c[0], c[1], twice, c[2], c[3], c[4], accumulate=1, slot=True, **c[5])
+        if deferred:
+            assert any(d["jobs"] for d in ops._defer.st.values()), "nothing was deferred"
+        ops.join_side()
+        torch.cuda.synchronize()
+        return outs + bouts + [twice]
+
+    ref = run(False)
+    with ops.deferring():
+        got = run(True)
+        for d in ops._defer.st.values():    # an arena far too small: every allocation past it flushes the pending jobs first
+            d["size"] = 1 << 16
+        ops._defer.high.clear()
+        ops._defer.ws = type(ops._defer.ws)()
+        got_small = run(True)
+    assert not any(d["jobs"] for d in ops._defer.st.values())
+    for a, b, c in zip(ref, got, got_small):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    w = torch.zeros(4, 4, device="cuda")
+    ops.wgrad_tn(cases[0][0], cases[0][1], torch.zeros(cases[0][6], device="cuda"), *cases[0][2:5], accumulate=0, slot=True, **cases[0][5])
+    assert not any(d["jobs"] for d in ops._defer.st.values()), "outside `deferring()` nothing is deferred"
