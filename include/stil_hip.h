@@ -126,6 +126,7 @@ typedef struct StilReduceJob {
 } StilReduceJob;
 int stil_reduce_job_bytes(void);
 int stil_wgrad_splits(int M, int N, int K, int tune);
+int stil_wgrad_force_splits(int s);   /* measurement hook (tests/tools/split_sweep.py): s > 0 forces s slabs; returns the previous setting */
 int stil_wgrad_tn_partial(const float* dY, const float* X, int M, int N, int K, int ldy, int ldx,
                           int srcH, int srcW, int srcC, int OH, int OW, int KH, int KW, int stride, int pad,
                           const float* x_bn, float* workspace, size_t workspace_bytes, int tune, void* stream);

@@ -116,7 +116,7 @@ class _Lib:
     def __getattr__(self, name):
         fn = getattr(self._dll, "stil_" + name)
         restype = self.protos["stil_" + name][0]
-        if restype is not ctypes.c_int or name in ("version", "device_count", "gemm_nt_variant", "gemm_nt_tile_rows", "gemm_nt_config", "weight_layout_job_bytes", "weight_layout_job_blocks", "gemm_nt_bstats_ok", "gemm_nt_force_splits", "reduce_job_bytes", "wgrad_splits", "colsum_chunks"):
+        if restype is not ctypes.c_int or name in ("version", "device_count", "gemm_nt_variant", "gemm_nt_tile_rows", "gemm_nt_config", "weight_layout_job_bytes", "weight_layout_job_blocks", "gemm_nt_bstats_ok", "gemm_nt_force_splits", "reduce_job_bytes", "wgrad_splits", "colsum_chunks", "wgrad_force_splits"):
             return fn
 
         def call(*args, meta=None):

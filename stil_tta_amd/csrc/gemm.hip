@@ -1625,13 +1625,24 @@ extern "C" int stil_gemm_nt(const float* A, const float* W, float* C, int M, int
 // block tile of the weight-gradient kernel: 22 = 128x128 (64x128 for N <= 64), 11 = 64x64; `tune` forces one (0 = automatic).
 // measured in situ (bench.py --breakdown, cold caches): 64x64 tiles win for N <= 256 (more blocks, fewer M-splits) except the
 // 1x1 convolutions with 128..256 outputs and K in 256..1024, where 128x128 halves the operand re-reads
-static inline int tn_variant(int N, int K, int tune) {
+// Small products (M < 8192 rows, or M < 32768 with fewer than 256 K outputs: what a per-GPU batch of 16-64 samples launches from
+// layer2 on, and the heads at any batch): 64x64 -- the 128x128 tile's few workgroups take a flat ~30 us there (tests/tools/
+// split_sweep.py tn, profiles/r05_split_sweep.txt: cardiac share of 16, 618 -> 424 us over the twenty products; B = 32: 1111 ->
+// 1031).  The B = 256 step keeps 128x128 on its M = 12544 ... 50176 products: moving the row bound to 16384 / 32768 / 65536 costs
+// it 0.7 / 1.2 / 1.6 % (paired, profiles/r05_experiments.txt 14).  STIL_WGRAD_SMALLM: the row bound (A/B knob).
+static inline int tn_variant(int M, int N, int K, int tune) {
+  static const int small_m = [] { const char* e = getenv("STIL_WGRAD_SMALLM"); return e ? atoi(e) : 8192; }();
   if (tune == 11 || tune == 22) return tune;
+  if (M < small_m || (M < 4 * small_m && (long)N * K < 262144)) return 11;
   if (N > 256) return 22;
   return (N >= 128 && K >= 256 && K <= 1024) ? 22 : 11;
 }
+// stil_wgrad_force_splits(s): measurement hook (tests/tools/split_sweep.py tn), s > 0 forces s slabs (slabs of >= 16 rows)
+static int g_force_wsplits = 0;
+extern "C" int stil_wgrad_force_splits(int s) { const int old = g_force_wsplits; g_force_wsplits = s; return old; }
 static int wgrad_splits(int M, int N, int K, int tune) {
-  const int tv = tn_variant(N, K, tune);
+  if (g_force_wsplits > 0) { const int m = M / 16 > 0 ? M / 16 : 1; const int s = g_force_wsplits < m ? g_force_wsplits : m; return s > 256 ? 256 : s; }
+  const int tv = tn_variant(M, N, K, tune);
   int tiles = tv == 11 ? cdiv(N, 64) * cdiv(K, 64) : cdiv(N, N <= 64 ? 64 : 128) * cdiv(K, 128);
   int want = cdiv(tv == 11 ? 2304 : 768, tiles);
   int maxs = M / 256 > 0 ? M / 256 : 1;
@@ -1669,7 +1680,7 @@ static int wgrad_tn_impl(const float* dY, const float* X, float* dW, int M, int 
   hipStream_t s = (hipStream_t)stream;
   const bool vec = p.vecY && p.vecX && (N % 4 == 0) && (K % 4 == 0);
   STIL_REQUIRE(!x_bn || (vec && srcC % 4 == 0), "stil_wgrad_tn: x_bn needs 16-byte aligned operands and Cin %% 4 == 0");
-  if (tn_variant(N, K, tune) == 11) {
+  if (tn_variant(M, N, K, tune) == 11) {
     dim3 grid(cdiv(N, 64) * cdiv(K, 64) * splits);
     if (x_bn) hipLaunchKernelGGL((gemm_tn_kernel<1, 1, true, true>), grid, dim3(256), 0, s, p);
     else if (vec) hipLaunchKernelGGL((gemm_tn_kernel<1, 1, true>), grid, dim3(256), 0, s, p);

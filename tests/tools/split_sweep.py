@@ -1,6 +1,8 @@
 """Split-K sweep of the NT products a SMALL per-GPU batch launches (B = 32 at 224 px; the cardiac share of 16 at 128 px): every shape
 with s = 1 (unsplit), the library's policy, and forced slice counts (stil_gemm_nt_force_splits), back-to-back launches on one stream
-as a hipGraph replay issues them.   usage: python tests/tools/split_sweep.py [b32|c16]        (measurement tool)"""
+as a hipGraph replay issues them.   usage: python tests/tools/split_sweep.py [b32|c16] [nt|tn]        (measurement tool)
+tn: the weight-gradient products dW = dY^T X of the same layers (stil_wgrad_tn: slab partials over M + the ordered reduce), block tile
+11 (64x64) / 22 (128x128) x forced slab counts (stil_wgrad_force_splits)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -46,6 +48,53 @@ def run(M, N, K, k, H, rounds=16):
         best = min(best, s0.elapsed_time(e0) / rounds)
     del g
     return best * 1e3
+if len(sys.argv) > 2 and sys.argv[2] == "tn":
+    def run_tn(M, N, K, k, H, tune, rounds=16):
+        dY = torch.randn(M, N, device="cuda")
+        if k == 1:
+            X = torch.randn(M, K, device="cuda"); geom = None
+        else:
+            C = K // 9; X = torch.randn(M // (H * H), H, H, C, device="cuda"); geom = (H, H, C, H, H, 3, 3, 1, 1)
+        dW = torch.empty(N, K, device="cuda") if k == 1 else torch.empty(N, K // 9, 3, 3, device="cuda")
+        ops.TUNE["wgrad"] = tune
+        ops.wgrad_tn(dY, X, dW, M, N, K, geom=geom); torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph(); side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.wgrad_tn(dY, X, dW, M, N, K, geom=geom)
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(rounds):
+                    ops.wgrad_tn(dY, X, dW, M, N, K, geom=geom)
+        torch.cuda.current_stream().wait_stream(side)
+        best = 1e9
+        for rep in range(4):
+            g.replay(); torch.cuda.synchronize()
+            s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record(); g.replay(); e0.record(); torch.cuda.synchronize()
+            best = min(best, s0.elapsed_time(e0) / rounds)
+        del g
+        ops.TUNE["wgrad"] = 0
+        return best * 1e3
+    TS = (1, 2, 4, 8, 16, 32, 64)
+    print(f"{which} tn: us per wgrad (partials + reduce); the forward shape (M, N, K) -> dW[N, K] summed over M;  policy | tile 11: s = " + " ".join(map(str, TS)) + " | tile 22: same")
+    tp = tb = 0.0
+    for (M, N, K, k, H) in SH:
+        L.wgrad_force_splits(0)
+        pol = run_tn(M, N, K, k, H, 0)
+        rows = {}
+        for tv in (11, 22):
+            rows[tv] = []
+            for s_ in TS:
+                if s_ > max(1, M // 64):
+                    rows[tv].append(None); continue
+                L.wgrad_force_splits(s_)
+                rows[tv].append(run_tn(M, N, K, k, H, tv))
+        L.wgrad_force_splits(0)
+        b = min(x for tv in rows for x in rows[tv] if x is not None)
+        tp += pol; tb += b
+        fmt = lambda r: " ".join("   -- " if x is None else f"{x:6.1f}" for x in r)
+        print(f"({M:6d},{N:5d},{K:5d},k{k}) policy s={L.wgrad_splits(M, N, K, 0):3d} {pol:6.1f} | {fmt(rows[11])} | {fmt(rows[22])} | best {b:6.1f} = {2.0 * M * N * K / b / 1e6:5.1f} TF")
+    print(f"sum: policy {tp:.1f} us, best per shape {tb:.1f} us")
+    sys.exit(0)
 print(f"{which}: us per launch;  tiles = 64x64 tiles, kt = 32-deep k-tiles;  columns: policy | forced s = " + " ".join(str(s) for s in SWEEP))
 tot_pol = tot_best = 0.0
 for (M, N, K, k, H) in SH:
