@@ -1438,11 +1438,13 @@ static int nt_splits(int M, int N, int K, int tune) {
     if (s > K / 64) s = K / 64;
     return s < 2 ? 1 : s;
   }
-  if (K < 256 || tiles >= 1536) return 1;
+  static const int max_tiles = [] { const char* e = getenv("STIL_GEMM_SPLIT_MAXTILES"); return e ? atoi(e) : 1536; }();   // A/B knobs
+  static const int big_target = [] { const char* e = getenv("STIL_GEMM_SPLIT_TARGET"); return e ? atoi(e) : 1536; }();
+  if (K < 256 || tiles >= max_tiles) return 1;
   const int kt = K / 32;
   int maxs, target;
   if (tiles < 256) { maxs = kt / 4; target = kt >= 64 ? 1536 : 512; }
-  else { if (kt < 36) return 1; maxs = kt / 12; target = 1536; }
+  else { if (kt < 36) return 1; maxs = kt / 12; target = big_target; }
   int s = cdiv(target, tiles);
   if (s > maxs) s = maxs;
   if (s > 8) s = 8;

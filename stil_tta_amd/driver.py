@@ -184,11 +184,11 @@ def synthetic_batch(field_lengths, num_classes: int, B: int, img_size: int, seed
 
 
 def wants_graph(batch: int, img_size: int) -> bool:
-    """Is a step of this per-GPU size bound by its ~1100 dependent launches rather than by the chip?  Measured (profiles/r05u_*,
-    one box, graph replay with deferred gradient reductions): the cardiac share of 16 samples per GPU at 128 px runs 21.5-23.5 ms
-    eager and 11.8 ms replayed; B = 64 at 128 px 23.4 eager / 22.8 replayed; B = 32 at 224 px is equal either way (24.0-24.8 /
-    24.4); from there on eager launches win (B = 256: 119 vs 138 ms).  The boundary is put at a million pixels per step."""
-    return batch * img_size * img_size <= 1048576
+    """Is a step of this per-GPU size bound by its ~1000 dependent launches rather than by the chip?  Measured (profiles/r05u_*,
+    r05w_*: one box each, graph replay with deferred gradient reductions): the cardiac share of 16 samples per GPU at 128 px runs
+    21.5-23.5 ms eager and 11.0 ms replayed; B = 64 at 128 px 23.4 eager / 22.1 replayed; B = 32 at 224 px 24.0-27.5 eager
+    (by host) / 23.9 replayed; from there on eager launches win (B = 256: 119 vs 138 ms).  The boundary is B = 32 at 224 px."""
+    return batch * img_size * img_size <= 32 * 224 * 224
 
 
 class GraphedTrainStep:
