@@ -488,6 +488,40 @@ def test_gemm_tune_policy_and_precision_flag_arithmetic(monkeypatch):
     assert L.gemm_nt_tile_rows(50176, 256, 22) == 128 and L.gemm_nt_variant(50176, 256, 21) == 21
 
 
+def test_small_batch_policies_host_side():
+    """Host-side decisions of the small-batch regime (no launch): the split-K policy of stil_gemm_nt as the workspace query reports
+    it (16 KB of tickets + tiles x slices x 16 KB of slabs; csrc/gemm.hip nt_splits, profiles/r05_split_sweep.txt), the measurement
+    hooks, the weight-gradient slab count, the StilReduceJob record ops._DeferredReduce packs, and driver.wants_graph's boundary."""
+    from stil_tta_amd import ops
+    from stil_tta_amd._lib import lib
+    from stil_tta_amd.driver import wants_graph
+    L = lib()
+
+    def slices(M, N, K):
+        b = L.gemm_nt_split_workspace_bytes(M, N, K, 0)
+        tiles = -(-M // 64) * -(-N // 64)
+        return 1 if b == 0 else (b - 16384) // (tiles * 16384)
+    assert slices(256, 512, 4608) == 8 and slices(256, 512, 2048) == 8 and slices(1024, 256, 512) == 4     # below one workgroup per CU
+    assert slices(4096, 128, 256) == 2 and slices(4096, 128, 1152) == 4 and slices(1568, 512, 4608) == 8
+    assert slices(2080, 512, 2048) == 5 and slices(6272, 256, 2304) == 4 and slices(25088, 128, 1152) == 2   # 256-1535 tiles: long K only
+    assert slices(6272, 256, 1024) == 1 and slices(25088, 128, 512) == 1 and slices(2080, 512, 512) == 1
+    for shape in ((12544, 512, 2048), (12544, 512, 4608), (16640, 512, 2048), (50176, 256, 2304), (802816, 64, 576), (256, 512, 128)):
+        assert slices(*shape) == 1, shape                                                                   # the B = 256 step: untouched
+    assert L.gemm_nt_force_splits(3) == 0
+    try:
+        assert slices(12544, 512, 2048) == 3 and slices(12544, 512, 128) == 1     # forced wherever a product can be split at all (K >= 256)
+    finally:
+        assert L.gemm_nt_force_splits(0) == 3
+    assert L.wgrad_splits(6272, 256, 2304, 0) == 16 and L.wgrad_splits(256, 512, 4608, 0) == 1
+    assert L.wgrad_force_splits(4) == 0 and L.wgrad_splits(6272, 256, 2304, 0) == 4 and L.wgrad_force_splits(0) == 4
+    assert L.colsum_chunks(1000) == 8 and L.reduce_job_bytes() == ops._DeferredReduce._JOB.size == 48
+    assert not ops._defer.active()
+    with ops.deferring():
+        assert ops._defer.active()
+    assert not ops._defer.active()
+    assert wants_graph(16, 128) and wants_graph(64, 128) and wants_graph(32, 224) and not wants_graph(64, 224) and not wants_graph(256, 224)
+
+
 # ---------------------------------------------------------------- fit-loop host logic (stil_tta_amd/fit.py)
 def test_fit_host_helpers():
     from stil_tta_amd import fit as F

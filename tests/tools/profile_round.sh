@@ -33,5 +33,6 @@ if [ -n "$OTHER_SHAPES" ]; then   # the other measurement shapes of SURVEY.md 8(
   timeout -k 10 200 python bench.py --img 128 --ncat 4 --ncon 13 --no-cpu-baseline > gpurun_out/$T/bench_native128.json 2>/dev/null
   timeout -k 10 200 python bench.py --variant cardiac --img 128 --batch 64 --no-cpu-baseline > gpurun_out/$T/bench_cardiac.json 2>/dev/null
   timeout -k 10 200 python bench.py --batch 32 --no-cpu-baseline > gpurun_out/$T/bench_b32.json 2>/dev/null
-  for f in saint native128 cardiac b32; do cut -c1-200 gpurun_out/$T/bench_$f.json; done
+  timeout -k 10 200 python bench.py --variant cardiac --img 128 --batch 16 --no-cpu-baseline > gpurun_out/$T/bench_cardiac16.json 2>/dev/null
+  for f in saint native128 cardiac b32 cardiac16; do cut -c1-200 gpurun_out/$T/bench_$f.json; done
 fi
