@@ -184,11 +184,12 @@ def synthetic_batch(field_lengths, num_classes: int, B: int, img_size: int, seed
 
 
 def wants_graph(batch: int, img_size: int) -> bool:
-    """Is a step of this per-GPU size bound by its ~1000 dependent launches rather than by the chip?  Measured (profiles/r05u_*,
-    r05w_*: one box each, graph replay with deferred gradient reductions): the cardiac share of 16 samples per GPU at 128 px runs
-    21.5-23.5 ms eager and 11.0 ms replayed; B = 64 at 128 px 23.4 eager / 22.1 replayed; B = 32 at 224 px 24.0-27.5 eager
-    (by host) / 23.9 replayed; from there on eager launches win (B = 256: 119 vs 138 ms).  The boundary is B = 32 at 224 px."""
-    return batch * img_size * img_size <= 32 * 224 * 224
+    """Is a step of this per-GPU size better replayed from a hipGraph (one queue, no host in the loop, but no second stream) than
+    launched eagerly (two streams, ~1000 launches at 18-20 us of host time each)?  Measured on one box (profiles/r05y5_*): cardiac
+    share of 16 samples per GPU at 128 px 18.2 ms eager / 11.0 replayed; B = 64 at 128 px 20.2 / 22.0; B = 32 at 224 px 21.1 /
+    23.9; B = 64 at 224 px 35.2 / 39.1; B = 256: 119 / 138.  Replay wins while the inline GPU time is below the host's ~18 ms per
+    step: the boundary is put at half a million pixels per step (32 samples at 128 px)."""
+    return batch * img_size * img_size <= 524288
 
 
 class GraphedTrainStep:

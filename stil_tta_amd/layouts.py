@@ -121,7 +121,7 @@ class WeightLayouts:
             self.params.append(param)
         self.fresh = False
         self.event = None             # set by refresh(publish=True)
-        self.waited = set()           # (device index, stream id) of the streams that have waited for `event`
+        self.waited = set()           # (device index, raw stream handle) of the streams that have waited for `event`
         self.version = -1             # slab._version at the last refresh
         self.pversion = {}            # id(param) -> param._version at the last refresh
         self.captured = False         # the last refresh was recorded inside a hipGraph capture
@@ -142,7 +142,7 @@ class WeightLayouts:
             st = torch.cuda.current_stream(self.slab.device)
             self.event = torch.cuda.Event()
             self.event.record(st)
-            self.waited = {(st.device_index, st.stream_id)}
+            self.waited = {(st.device_index, st.cuda_stream)}
         # freshness is tied to the DATA, not only to the call sites that remember to invalidate: writes to the slab or to a
         # parameter that go through PyTorch (checkpoint restores, collectives into the slab, tests) move their version counters
         self.version = self.slab._version

@@ -35,11 +35,11 @@ class TeacherPipe:
 
     def published(self):
         ev = torch.cuda.Event()
-        ev.record()
+        ev.record(ops.current_stream_obj())
         self.events.append(ev)
 
     def before_teacher_bn(self, bn: nn.BatchNorm2d):
-        torch.cuda.current_stream().wait_event(self.events[self.i])
+        ops.current_stream_obj().wait_event(self.events[self.i])
         self.i += 1
         if self.eman:
             f = self.flat

@@ -18,11 +18,47 @@ _vp = ctypes.c_void_p
 
 
 def _p(t: Optional[torch.Tensor]):
-    return None if t is None else _vp(t.data_ptr())
+    return None if t is None else t.data_ptr()   # ctypes takes the integer for a void* argument (no c_void_p object per operand)
+
+
+# The current stream's raw handle straight from the C binding: torch.cuda.current_stream() builds a Stream object through
+# _get_device_index -> is_available -> os.environ on every call (5-7 us; ~1400 calls per step, a quarter of the host time of the
+# launch-bound small-batch steps: tests/tools/host_profile.py).
+_raw_current_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_current_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
+def _raw_stream(device=None) -> int:
+    """hipStream_t of the current stream of `device` (a torch.device / index / None = current device) as an integer"""
+    if _raw_current_stream is None or _current_device is None:
+        return torch.cuda.current_stream(device).cuda_stream
+    if device is None:
+        idx = _current_device()
+    elif isinstance(device, int):
+        idx = device
+    else:
+        idx = device.index if device.index is not None else _current_device()
+    return _raw_current_stream(idx)
 
 
 def _stream():
-    return _vp(torch.cuda.current_stream().cuda_stream)
+    return _raw_stream()
+
+
+_STREAM_OBJS = {}
+
+
+def current_stream_obj(device=None) -> "torch.cuda.Stream":
+    """torch.cuda.current_stream(device), cached by raw handle (the Stream object costs 5-7 us to build; Event.record() / .wait()
+    without an explicit stream build one too)"""
+    if _raw_current_stream is None or _current_device is None:
+        return torch.cuda.current_stream(device)
+    idx = _current_device() if device is None else (device if isinstance(device, int) else (device.index if device.index is not None else _current_device()))
+    key = (idx, _raw_current_stream(idx))
+    st = _STREAM_OBJS.get(key)
+    if st is None:
+        st = _STREAM_OBJS[key] = torch.cuda.current_stream(idx)
+    return st
 
 
 def _chk(*ts):
@@ -46,10 +82,11 @@ class _Workspace:
         self.captured = set()    # keys whose current buffer a captured graph may hold
         self.pinned = []         # superseded buffers a captured graph may still address
 
-    def get(self, nbytes: int, device) -> torch.Tensor:
+    def get(self, nbytes: int, device, stream=None) -> torch.Tensor:
+        """`stream` (a torch Stream): the stream the buffer will be used on when that is not the current one -- a (re)allocation
+        then happens under it, so the block belongs to that stream's pool"""
         nbytes = max(int(nbytes), 256)
-        st = torch.cuda.current_stream(device)
-        key = (device, st.stream_id, st.cuda_stream)
+        key = (device, _raw_stream(device) if stream is None else stream.cuda_stream)
         b = self.buf.get(key)
         capturing = torch.cuda.is_current_stream_capturing()
         if b is None or b.numel() < nbytes:
@@ -57,7 +94,11 @@ class _Workspace:
                 self.pinned.append(b)
                 self.captured.discard(key)
             n = int(nbytes * (1.5 if self.zero else 1.25)) + 4096
-            b = (torch.zeros if self.zero else torch.empty)(n, dtype=torch.uint8, device=device)
+            if stream is None:
+                b = (torch.zeros if self.zero else torch.empty)(n, dtype=torch.uint8, device=device)
+            else:
+                with torch.cuda.stream(stream):
+                    b = (torch.zeros if self.zero else torch.empty)(n, dtype=torch.uint8, device=device)
             self.buf[key] = b
         if capturing:
             self.captured.add(key)
@@ -182,10 +223,10 @@ def cached_layout(param, attr: str, key=None):
     if plan is None or not plan.current(param):
         return None
     if plan.event is not None:      # refreshed on another stream: this stream waits for it once
-        st = torch.cuda.current_stream(plan.slab.device)
-        sk = (st.device_index, st.stream_id)
+        dev_ = plan.slab.device
+        sk = (dev_.index, _raw_stream(dev_))
         if sk not in plan.waited:
-            st.wait_event(plan.event)
+            current_stream_obj(dev_).wait_event(plan.event)
             plan.waited.add(sk)
     v = getattr(param, attr, None)
     if v is None or key is None:
@@ -230,10 +271,10 @@ class _DeferredReduce:
         return self.mode == "1" or self.forced > 0
 
     def _state(self, device):
-        st = torch.cuda.current_stream(device)
-        key = (device, st.stream_id, st.cuda_stream)
+        key = (device, _raw_stream(device))
         d = self.st.get(key)
         if d is None:
+            st = torch.cuda.current_stream(device)
             d = self.st[key] = dict(stream=st, device=device, size=max(256 << 20, int(1.25 * self.high.get(device, 0))), off=0, jobs=[], dsts=set())
         return d
 
@@ -355,8 +396,9 @@ def gemm_nt(A, W, M, N, K, *, lda=None, ldb=None, out=None, ldc=None, geom=None,
     return out
 
 
-def wgrad_tn(dY, X, dW, M, N, K, *, ldy=None, ldx=None, geom=None, Kdst=None, accumulate=0, x_bn=None, slot=False):
-    """`slot`: dW is a view of the gradient slab -- its slab reduction may be deferred to the next join_side() (_DeferredReduce)"""
+def wgrad_tn(dY, X, dW, M, N, K, *, ldy=None, ldx=None, geom=None, Kdst=None, accumulate=0, x_bn=None, slot=False, stream=None):
+    """`slot`: dW is a view of the gradient slab -- its slab reduction may be deferred to the next join_side() (_DeferredReduce).
+    `stream` (a torch Stream, not with a deferred reduction): launch there instead of on the current stream -- the caller orders it."""
     if geom is None:
         geom = (1, 1, K, 1, 1, 1, 1, 1, 0)
     ldy = N if ldy is None else ldy
@@ -370,8 +412,9 @@ def wgrad_tn(dY, X, dW, M, N, K, *, ldy=None, ldx=None, geom=None, Kdst=None, ac
         L.wgrad_tn_partial(_p(dY), _p(X), M, N, K, ldy, ldx, *geom, _p(x_bn), a, nb, TUNE["wgrad"], _stream(), meta=meta)
         _defer.add(dY.device, a, dW, L.wgrad_splits(M, N, K, TUNE["wgrad"]), N, K, geom[2], geom[5] * geom[6], Kdst, accumulate, 1.0)
         return
-    w = _ws.get(nb, dY.device)
-    L.wgrad_tn(_p(dY), _p(X), _p(dW), M, N, K, ldy, ldx, *geom, Kdst, accumulate, _p(x_bn), _p(w), nb, TUNE["wgrad"], _stream(), meta=meta)
+    w = _ws.get(nb, dY.device, stream)
+    L.wgrad_tn(_p(dY), _p(X), _p(dW), M, N, K, ldy, ldx, *geom, Kdst, accumulate, _p(x_bn), _p(w), nb, TUNE["wgrad"],
+               _stream() if stream is None else stream.cuda_stream, meta=meta)
 
 
 # STIL_WGRAD_SIDE=0: weight gradients stay on the main stream while the EMA teacher keeps the side stream (A/B measurements of the
@@ -386,16 +429,25 @@ def wgrad_param(param, dY, X, M, N, K, **kw):
     side = side_stream(dY.device) if (slot is not None and _WGRAD_SIDE) else None
     if side is None:
         return _grad_into(param, lambda dst, acc, slot_: wgrad_tn(dY, X, dst, M, N, K, accumulate=acc, slot=slot_, **kw))
-    main = torch.cuda.current_stream()
+    main = current_stream_obj(dY.device)
     _side.retire()
-    if main != side:
-        side.wait_stream(main)
-    with torch.cuda.stream(side):
-        wgrad_tn(dY, X, slot, M, N, K, accumulate=1, slot=True, **kw)
+    if main.cuda_stream == side.cuda_stream or _defer.active():
         if main != side:
-            ev = torch.cuda.Event()
-            ev.record(side)
-            _side.keep.append((ev, (dY, X, kw.get("x_bn"))))
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            wgrad_tn(dY, X, slot, M, N, K, accumulate=1, slot=True, **kw)
+            if main != side:
+                ev = torch.cuda.Event()
+                ev.record(side)
+                _side.keep.append((ev, (dY, X, kw.get("x_bn"))))
+    else:   # the launch goes to the side stream by handle: no switch of torch's current stream (~10 us of host time per product)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        side.wait_event(fork)
+        wgrad_tn(dY, X, slot, M, N, K, accumulate=1, slot=True, stream=side, **kw)
+        ev = torch.cuda.Event()
+        ev.record(side)
+        _side.keep.append((ev, (dY, X, kw.get("x_bn"))))
     _touch(param)
     return None
 

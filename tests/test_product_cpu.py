@@ -519,7 +519,7 @@ def test_small_batch_policies_host_side():
     with ops.deferring():
         assert ops._defer.active()
     assert not ops._defer.active()
-    assert wants_graph(16, 128) and wants_graph(64, 128) and wants_graph(32, 224) and not wants_graph(64, 224) and not wants_graph(256, 224)
+    assert wants_graph(16, 128) and wants_graph(32, 128) and not wants_graph(64, 128) and not wants_graph(32, 224) and not wants_graph(256, 224)
 
 
 # ---------------------------------------------------------------- fit-loop host logic (stil_tta_amd/fit.py)
