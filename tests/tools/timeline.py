@@ -37,3 +37,29 @@ for s, e, q, n in ev[1:]:
 gaps.sort(reverse=True)
 print("  largest idle gaps (us, next kernel):", [(round(g / 1e3, 1), n) for g, n in gaps[:8]])
 print("  idle total: %.3f ms in %d gaps" % (sum(g for g, _ in gaps) / 1e6, len(gaps)))
+# per queue: busy time, and how its busy time splits by what the OTHER queues run meanwhile (GEMM / other kernel / nothing)
+qs = sorted(byq)
+iv = {q: sorted((s, e, n) for s, e, qq, n in ev if qq == q) for q in qs}
+def classify(n):
+    return "gemm" if "gemm" in n or "attn" in n else "other"
+marks = []
+for s, e, q, n in ev:
+    marks.append((s, 0, q, classify(n))); marks.append((e, 1, q, classify(n)))
+marks.sort(key=lambda m: (m[0], -m[1]))
+cur = {}
+last = t0
+acc2 = collections.defaultdict(float)
+for t, kind, q, c in marks:
+    if t > last and cur:
+        for q1, c1 in cur.items():
+            others = [c2 for q2, c2 in cur.items() if q2 != q1]
+            o = "alone" if not others else ("with gemm" if "gemm" in others else "with other")
+            acc2[(q1, c1, o)] += t - last
+    last = t
+    if kind == 0:
+        cur[q] = c
+    else:
+        cur.pop(q, None)
+print("  queue, kernel class, what the other queues run meanwhile: ms")
+for k in sorted(acc2):
+    print(f"    queue {k[0]} {k[1]:6s} {k[2]:11s} {acc2[k] / 1e6:8.3f}")
