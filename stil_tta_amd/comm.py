@@ -215,7 +215,7 @@ class GradExchange:
                 self.comm_stream = torch.cuda.Stream(slab.device)
             cs = self.comm_stream
             cs.wait_stream(torch.cuda.current_stream(slab.device))   # BN / LN / bias gradients (main stream)
-            for st in ops._side.streams.values():                    # weight gradients (side stream)
+            for st in ops._side.all_streams():                       # weight gradients (side stream), the tabular branch's own gradients
                 if st.device == slab.device:
                     cs.wait_stream(st)
             with torch.cuda.stream(cs):

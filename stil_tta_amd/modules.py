@@ -436,14 +436,19 @@ class DisCoAttentionBackbone(nn.Module):
         self.classifier_imaging = nn.Linear(C * 2, hp.num_classes)
         self.classifier_tabular = nn.Linear(C * 2, hp.num_classes)
 
-    def forward_all(self, x, train: Optional[bool] = None, mi_masks=None, cache=None, x_i=None):
+    def tabular_tokens(self, x_tab, train: bool, mi_masks=None):
+        """the tabular encoder alone -> [B, Nt+1, Dt] (STiLModel.training_step issues it on its own stream, beside the image encoder)"""
+        return self.encoder_tabular.run(x_tab)
+
+    def forward_all(self, x, train: Optional[bool] = None, mi_masks=None, cache=None, x_i=None, x_t=None):
         """-> (out_m, out_i, out_t, x_si_enhance, mean(x_si), x_ai, x_st_enhance, mean(x_st), x_at, x_c);
-        x_i: image tokens when the caller already ran the image encoder (ResNet.run_pair)."""
+        x_i / x_t: image / tabular tokens when the caller already ran that encoder (ResNet.run_pair, tabular_tokens)."""
         train = self.training if train is None else train
         x_img, x_tab = x[0], x[1]
         if x_i is None:
             x_i = self.encoder_imaging.run(x_img, train, cache)       # [B, Ni, pooled]
-        x_t = self.encoder_tabular.run(x_tab)                         # [B, Nt+1, Dt]
+        if x_t is None:
+            x_t = self.tabular_tokens(x_tab, train, mi_masks)         # [B, Nt+1, Dt]
         x_si = self.projection_si.run(x_i)
         x_ai = self.projection_ai.run(ops.tokmean(x_i))
         x_st = self.projection_st.run(x_t[:, 1:, :].contiguous())

@@ -150,6 +150,14 @@ class _SideStream:
         self.enabled = os.environ.get("STIL_WGRAD_STREAM", "1") != "0"
         self.in_capture = os.environ.get("STIL_GRAPH_SIDE", "0") != "0"
         self.streams = {}
+        # the BRANCH stream (OPT-IN, STIL_BRANCH_STREAM=1): the student's tabular encoder runs its forward there, beside the image
+        # encoder on the main stream, and -- the autograd engine runs a node's backward on the stream of its forward -- its backward
+        # too, so that the attention / LayerNorm kernels of that branch hide under the image branch's GEMMs instead of running alone
+        # on the main stream (profiles/r05y8_timeline_b256.txt: ~6 ms of non-GEMM kernels run alone).  Bit-identical, and measured
+        # SLOWER on the step: 2062-2082 samples/s against 2074-2098 without, paired -- a third queue of matrix-bound kernels takes
+        # the dominant GEMM from 65 to 50 TF/s while it co-runs and buys nothing in aggregate (profiles/r05_experiments.txt 15).
+        self.use_branch = os.environ.get("STIL_BRANCH_STREAM", "0") != "0"
+        self.branch = {}
         # (event recorded on the side stream after a launch, the tensors that launch reads).  Holding the references
         # (1) keeps the autograd engine from accumulating IN PLACE into a gradient buffer a pending side-stream kernel
         # still has to read (the engine only does that when it holds the last reference), and (2) keeps the allocator
@@ -174,6 +182,15 @@ class _SideStream:
             st = self.streams[device] = torch.cuda.Stream(device)
         return st
 
+    def get_branch(self, device):
+        st = self.branch.get(device)
+        if st is None:
+            st = self.branch[device] = torch.cuda.Stream(device)
+        return st
+
+    def all_streams(self):
+        return list(self.streams.values()) + list(self.branch.values())
+
 
 _side = _SideStream()
 
@@ -181,9 +198,17 @@ _side = _SideStream()
 def join_side():
     """Make the current stream wait for every side-stream launch issued so far (deferred gradient reductions included)."""
     _defer.flush()
-    for st in _side.streams.values():
+    for st in _side.all_streams():
         torch.cuda.current_stream(st.device).wait_stream(st)
     _side.retire(everything=True)   # the current stream is now ordered after every side-stream read
+
+
+def branch_stream(device):
+    """The branch stream of `device` (see _SideStream), or None when there is no side stream now (overlap off, single-stream
+    profiling, any hipGraph capture) or STIL_BRANCH_STREAM=0."""
+    if not _side.use_branch or side_stream(device) is None or torch.cuda.is_current_stream_capturing():
+        return None
+    return _side.get_branch(device)
 
 
 def side_stream(device):

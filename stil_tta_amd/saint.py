@@ -196,13 +196,17 @@ class SaintBackbone(nn.Module):
     def forward_tabular(self, x_t, masks=None):
         return saint_forward_tabular(self, x_t, masks)
 
-    def forward_all(self, x, train: Optional[bool] = None, mi_masks=None, cache=None, x_i=None):
+    def tabular_tokens(self, x_tab, train: bool, mi_masks=None):
+        sm = None if (mi_masks is None or not train) else mi_masks.get("saint")
+        return self.forward_tabular(x_tab, sm)
+
+    def forward_all(self, x, train: Optional[bool] = None, mi_masks=None, cache=None, x_i=None, x_t=None):
         train = self.training if train is None else train
         x_img, x_tab = x[0], x[1]
         if x_i is None:
             x_i = self.encoder_imaging.run(x_img, train, cache)
-        sm = None if (mi_masks is None or not train) else mi_masks.get("saint")
-        x_t = self.forward_tabular(x_tab, sm)
+        if x_t is None:
+            x_t = self.tabular_tokens(x_tab, train, mi_masks)
         x_si = self.projection_si.run(x_i)
         x_ai = self.projection_ai.run(ops.tokmean(x_i))
         x_st = self.projection_st.run(x_t[:, 1:, :].contiguous())

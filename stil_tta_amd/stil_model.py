@@ -386,11 +386,21 @@ class STiLModel(_Base):
             else:
                 main = torch.cuda.current_stream()
                 side.wait_event(pipe.start)
+                # the student's tabular encoder on the branch stream, beside the image encoder (its backward follows it there: ops._SideStream)
+                branch = ops.branch_stream(dev)
+                xt_s = None
+                if branch is not None:
+                    branch.wait_stream(main)
+                    with torch.cuda.stream(branch):
+                        xt_s = self.model.tabular_tokens(x_tab, True, masks)
                 xi_s, xi_t = self.model.encoder_imaging.run_pair(self.ema.encoder_imaging, x_img, cache, side)
                 with torch.no_grad(), torch.cuda.stream(side):  # the rest of the teacher has no hand-over: issue it first
                     t = self.ema.forward_all((x_img, x_tab), train=False, cache=cache, x_i=xi_t)
                     feat_m_e, _, _ = self.project_3features(torch.cat((t[3], t[9], t[6]), dim=1))
-                s = self.model.forward_all((x_img, x_tab), train=True, mi_masks=masks, cache=cache, x_i=xi_s)
+                if branch is not None:
+                    main.wait_stream(branch)
+                    xt_s.record_stream(main)
+                s = self.model.forward_all((x_img, x_tab), train=True, mi_masks=masks, cache=cache, x_i=xi_s, x_t=xt_s)
                 main.wait_stream(side)
                 for tt in (*t, feat_m_e):
                     tt.record_stream(main)

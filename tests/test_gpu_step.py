@@ -836,15 +836,17 @@ def test_graphed_step_replays_the_eager_step_bit_for_bit(two_streams):
 
 
 def test_side_stream_pipeline_is_bit_exact():
-    """Teacher beside the student (layer-wise BN hand-over) + weight gradients on the side stream produce exactly the bits
-    of the single-stream order "student, momentum_update_ema, teacher, backward" (same kernels, same operands)."""
+    """Teacher beside the student (layer-wise BN hand-over) + weight gradients on the side stream + the student's tabular encoder
+    (forward and, through autograd, backward) on the branch stream produce exactly the bits of the single-stream order "student,
+    momentum_update_ema, teacher, backward" (same kernels, same operands); also with the (opt-in) branch stream switched off, the default."""
     from stil_tta_amd import STiLModel, ops
     from stil_tta_amd.driver import synthetic_batch, train_step
     from stil_tta_amd.flat import StilAdam
     fl = [3, 4] + [1] * 3
     outs = []
-    for enabled in (False, True):
-        ops._side.enabled = enabled
+    for enabled, branch in ((False, True), (True, True), (True, False)):
+        ops._side.enabled, ops._side.use_branch = enabled, branch
+        ops._side.branch.clear()
         try:
             torch.manual_seed(0)
             m = STiLModel(dict(model="resnet18", embedding_dim=512, field_lengths=fl, num_classes=5, start_epoch=0, batch_size=16, th1=0.3))
@@ -855,12 +857,14 @@ def test_side_stream_pipeline_is_bit_exact():
             losses = [float(train_step(m, opt, batch)) for _ in range(3)]
             torch.cuda.synchronize()
             outs.append((losses, m.flat.params.clone(), m.flat.ema.clone(), m.flat.grads.clone(), m.last["y_hat_m_e"].clone(), m.prototypes_sum.clone()))
+            assert bool(ops._side.branch) == (enabled and branch), "the branch stream runs exactly when the side stream does and it is on"
         finally:
-            ops._side.enabled = True
-    a, b = outs
-    assert a[0] == b[0]
-    for x, y in zip(a[1:], b[1:]):
-        assert torch.equal(x, y)
+            ops._side.enabled, ops._side.use_branch = True, False
+    a = outs[0]
+    for b in outs[1:]:
+        assert a[0] == b[0]
+        for x, y in zip(a[1:], b[1:]):
+            assert torch.equal(x, y)
 
 
 @pytest.mark.parametrize("label,over,B", [
