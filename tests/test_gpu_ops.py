@@ -1049,11 +1049,12 @@ def test_gemm_split_k_is_the_unsplit_product_and_deterministic(ops, M, N, K, con
         ops._SPLITK = default_split
 
 
-def test_deferred_gradient_reductions_equal_the_immediate_ones_bit_for_bit(ops):
+def test_deferred_gradient_reductions_equal_the_immediate_ones_bit_for_bit(ops, monkeypatch):
     """ops._DeferredReduce (graph-replayed small batches): weight-gradient / bias-sum partials stay in the arena and ONE multi-job
     launch (stil_reduce_jobs) finishes them at join_side() -- the same bits as stil_wgrad_tn / stil_colsum, for convolution layouts
     (taps > 1), truncated rows (Kdst < K: the padded stem), unaligned shapes (scalar body), two contributions to one slot (flushed in
     order), more jobs than one launch carries (48) and an arena too small for the step (flush + regrow in the middle)."""
+    monkeypatch.setattr(ops._defer, "mode", "auto")   # whatever STIL_REDUCE_DEFER says: deferred only inside `deferring()` here
     g = torch.Generator().manual_seed(5)
     cases = []    # (dY, X, M, N, K, kwargs, dW shape)
     for (Cin, Cout, k, H) in ((32, 64, 3, 9), (64, 48, 1, 14), (16, 32, 3, 7), (128, 256, 1, 4)):
